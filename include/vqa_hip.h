@@ -1,0 +1,209 @@
+/*
+ * vqa_hip.h -- C ABI of libvqahip.so, the MI355X (gfx950) statevector engine
+ * for batched evaluation of parameterized circuits and their parameter-shift
+ * gradients.
+ *
+ * The reference (Qulacs-Osaka/VQA, pure Python) reaches this arithmetic through
+ * a duck-typed skqulacs LearningCircuit and qulacs objects, one data sample at
+ * a time.  Each entry point below names the reference call sites it replaces
+ * (paths relative to the reference checkout).
+ *
+ * Conventions (qulacs): basis index bit k <-> qubit k (qubit 0 is the least
+ * significant bit); RX/RY/RZ(a) = exp(+i a/2 P):
+ *   RX = [[c, i s], [i s, c]]   RY = [[c, s], [-s, c]]   RZ = diag(e^{+ia/2}, e^{-ia/2})
+ * with c = cos(a/2), s = sin(a/2).  CNOT(control, target); CZ symmetric.
+ * Every circuit starts from |0...0>.
+ *
+ * Error model: every function returns VQA_OK (0) or a negative VQA_E* code,
+ * never throws or aborts across the boundary, and leaves outputs untouched on
+ * error.  vqa_last_error() returns a thread-local message for the last
+ * failure on the calling thread.
+ *
+ * Ownership: the caller owns every pointer it passes and keeps it alive until
+ * the call returns (host-pointer entry points are synchronous) or until the
+ * stream work has completed (device-pointer entry points are asynchronous on
+ * the caller's stream).  The library owns the memory behind opaque handles;
+ * handles are immutable after creation, may be shared between threads, and
+ * are freed only by the matching *_destroy.
+ */
+#ifndef VQA_HIP_H
+#define VQA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VQA_ABI_VERSION 1
+
+/* error codes */
+#define VQA_OK            0
+#define VQA_EINVAL       (-1)  /* bad argument (message says which) */
+#define VQA_ENOMEM       (-2)  /* host or device allocation failed */
+#define VQA_EHIP         (-3)  /* a HIP runtime call failed */
+#define VQA_EUNSUPPORTED (-4)  /* valid request outside what the engine implements */
+#define VQA_ENODEVICE    (-5)  /* no usable GPU */
+
+/* gate kinds of the flat op table */
+#define VQA_GATE_H     0
+#define VQA_GATE_X     1
+#define VQA_GATE_Y     2
+#define VQA_GATE_Z     3
+#define VQA_GATE_RX    4
+#define VQA_GATE_RY    5
+#define VQA_GATE_RZ    6
+#define VQA_GATE_CNOT  7   /* q0 = target, q1 = control */
+#define VQA_GATE_CZ    8   /* q0, q1 symmetric */
+
+/* where a rotation takes its angle from */
+#define VQA_SRC_CONST  0   /* angle = offset */
+#define VQA_SRC_THETA  1   /* angle = coef * (theta[idx] + shift if idx is the shifted parameter) + offset */
+#define VQA_SRC_INPUT  2   /* angle = coef * input_angles[sample, idx] + offset */
+
+/*
+ * One gate of the submitted (unfused) gate list.  Replaces the gate objects a
+ * LearningCircuit accumulates through add_H_gate / add_CNOT_gate / add_gate(CZ)
+ * / add_input_RZ_gate / add_parametric_R{X,Y,Z}_gate
+ * (vqa/QNN/QML_utils.py:47-98, 114-163).
+ */
+typedef struct vqa_op {
+    int32_t kind;     /* VQA_GATE_* */
+    int32_t q0;       /* target qubit */
+    int32_t q1;       /* control / second qubit, -1 when unused */
+    int32_t src;      /* VQA_SRC_* (rotations only) */
+    int32_t idx;      /* index into theta[] or into one row of input_angles */
+    int32_t reserved; /* must be 0 */
+    double  coef;     /* multiplies the sourced value */
+    double  offset;   /* added to it (the whole angle for VQA_SRC_CONST) */
+} vqa_op;
+
+typedef struct vqa_circuit vqa_circuit;   /* opaque: gate list + compiled device programs */
+typedef struct vqa_obs vqa_obs;           /* opaque: a real linear combination of Pauli strings */
+
+/* ---- library ---------------------------------------------------------- */
+
+/* ABI version (VQA_ABI_VERSION of the built library). */
+int vqa_version(void);
+/* Number of visible GPUs, or a negative VQA_E* code. */
+int vqa_device_count(void);
+/* Message for the last error on this thread ("" if none). Never NULL. */
+const char* vqa_last_error(void);
+/* Block until all work the library queued on its own stream of `device` is done. */
+int vqa_sync(int device);
+
+/* ---- circuits ---------------------------------------------------------- */
+
+/*
+ * Build a circuit from a flat op table.  n_theta is the number of trainable
+ * parameters P (what len(circuit.get_parameters()) returns in the reference,
+ * vqa/QNN/myQNNs_base.py:290), n_input the row length of input_angles.
+ * Replaces LearningCircuit construction (vqa/QNN/QML_utils.py:33-164).
+ */
+int vqa_circuit_create(int n_qubits, const vqa_op* ops, int n_ops,
+                       int n_theta, int n_input, vqa_circuit** out);
+int vqa_circuit_destroy(vqa_circuit* c);
+/* Introspection: qubits, ops, parameters, inputs of a circuit. */
+int vqa_circuit_info(const vqa_circuit* c, int* n_qubits, int* n_ops,
+                     int* n_theta, int* n_input);
+
+/* ---- observables -------------------------------------------------------- */
+
+/*
+ * sum_t coefs[t] * P_t with P_t the Pauli string that has Z on the set bits of
+ * zmasks[t] only, X on the set bits of xmasks[t] only, and Y where both are
+ * set; both masks 0 = identity (contributes coefs[t] * <psi|psi>).  xmasks may
+ * be NULL (all Z-strings).  Replaces qulacs Observable(n) + add_operator(coef,
+ * "Z i Z j") (vqa/QNN/myQNNs_base.py:353-361, vqa/QNN/myQNNs_classifier.py:295-339).
+ */
+int vqa_observable_create(int n_qubits, const double* coefs,
+                          const uint64_t* zmasks, const uint64_t* xmasks,
+                          int n_terms, vqa_obs** out);
+int vqa_observable_destroy(vqa_obs* o);
+
+/* ---- batched evaluation ------------------------------------------------- */
+
+/*
+ * Evaluate E circuit instances.  Instance e runs the circuit on sample
+ * sample_idx[e] (a row of input_angles[B, n_input], row-major) with parameters
+ * theta[P], where theta[shift_param[e]] is replaced by theta[..] + shift_val[e]
+ * (shift_param[e] = -1: no shift), and writes
+ *   out_expect[e * n_obs + o]            = Re <psi_e| obs[o] |psi_e>
+ *   out_marginal[e * 2^n_marg_bits + m]  = Prob(lowest n_marg_bits qubits read m)
+ * out_marginal may be NULL when n_marg_bits == 0; out_expect may be NULL when
+ * n_obs == 0.  sample_idx may be NULL when E == B (instance e uses sample e);
+ * shift_param/shift_val may both be NULL (no shifts).
+ *
+ * One instance replaces circuit.update_parameters(theta) + circuit.run(x) +
+ * Observable.get_expectation_value(state) (vqa/QNN/myQNNs_base.py:692-704,
+ * 907-914, 1022-1034, 1110-1125) and, through the marginal, the only use the
+ * reference makes of state.sampling(): samples % 2 / samples % 4
+ * (vqa/QNN/myQNNs_base.py:725-727, vqa/QNN/myQNNs_classifier.py:613-619).
+ *
+ * Host pointers; synchronous; runs on GPU `device`.
+ */
+int vqa_eval_batch(vqa_circuit* c, int device,
+                   const double* theta, const double* input_angles, int B,
+                   const int32_t* sample_idx, const int32_t* shift_param,
+                   const double* shift_val, int64_t E,
+                   const vqa_obs* const* obs, int n_obs, int n_marg_bits,
+                   double* out_expect, double* out_marginal);
+
+/*
+ * Same computation with every data pointer a DEVICE pointer on `device`, queued
+ * on `stream` (a hipStream_t; NULL = the library's own stream for the device)
+ * and not waited for.  Inputs may stay resident in HBM between calls.
+ */
+int vqa_eval_batch_dev(vqa_circuit* c, int device, void* stream,
+                       const double* d_theta, const double* d_input_angles, int B,
+                       const int32_t* d_sample_idx, const int32_t* d_shift_param,
+                       const double* d_shift_val, int64_t E,
+                       const vqa_obs* const* obs, int n_obs, int n_marg_bits,
+                       double* d_out_expect, double* d_out_marginal);
+
+/*
+ * Full parameter-shift sweep for n_sel samples: for sample s = sel[j] (sel NULL:
+ * s = j, n_sel <= B) evaluates the 2P+1 instances
+ *   k = 0        : theta
+ *   k = 2i + 1   : theta + shift * e_i
+ *   k = 2i + 2   : theta - shift * e_i          (i = 0..P-1)
+ * and writes out_expect[(j * (2P+1) + k) * n_obs + o] and
+ * out_marginal[(j * (2P+1) + k) * 2^n_marg_bits + m].  The instance list is
+ * generated on the device.  Replaces the loop nest of the parameter-shift
+ * oracles: base evaluation + for each parameter the +/- pi/2 pair over the
+ * mini-batch (vqa/QNN/myQNNs_base.py:1370-1394, 1469-1530;
+ * vqa/QNN/myQNNs_classifier.py:1116-1156).
+ */
+int vqa_psr_full(vqa_circuit* c, int device,
+                 const double* theta, const double* input_angles, int B,
+                 const int32_t* sel, int n_sel, double shift,
+                 const vqa_obs* const* obs, int n_obs, int n_marg_bits,
+                 double* out_expect, double* out_marginal);
+
+int vqa_psr_full_dev(vqa_circuit* c, int device, void* stream,
+                     const double* d_theta, const double* d_input_angles, int B,
+                     const int32_t* d_sel, int n_sel, double shift,
+                     const vqa_obs* const* obs, int n_obs, int n_marg_bits,
+                     double* d_out_expect, double* d_out_marginal);
+
+/*
+ * Final state of ONE instance, interleaved (re, im) doubles, 2 * 2^n values,
+ * host pointer.  For plumbing tests of the per-sample circuit.run(x) shim
+ * (vqa/QNN/myQNNs_base.py:913); not a hot-path call.
+ */
+int vqa_statevector(vqa_circuit* c, int device,
+                    const double* theta, const double* input_row,
+                    int shift_param, double shift_val, double* out_state);
+
+/*
+ * Engine selection for circuits created afterwards on this thread's process:
+ * 0 = automatic, 1 = LDS gate-by-gate engine (n <= 13), 2 = register-blocked
+ * fused engine (n <= 12), 3 = HBM streaming engine (any n).  For tests and
+ * benchmarks that compare engines; not part of the reference interface.
+ */
+int vqa_set_engine(int engine);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VQA_HIP_H */

@@ -1,0 +1,168 @@
+"""GPU parity: the HIP engines, called through the C ABI, against the CPU
+oracle on the same seeded inputs.  Tolerance 1e-10 absolute in fp64 (the
+figure the engine is specified to)."""
+import numpy as np
+import pytest
+
+from vqa_amd import LearningCircuit, Observable, _lib
+from vqa_amd.qml_utils import (create_ibm_HEA_ansatz, create_jerbi_ansatz,
+                               create_ry_cz_ansatz, create_ry_rz_cz_ansatz)
+from oracle import cpu_oracle
+from helpers import TOL, obs_tuples, random_circuit, random_observables
+
+pytestmark = pytest.mark.gpu
+
+ENGINES = {"lds": 1, "reg": 2, "hbm": 3}
+
+
+@pytest.fixture(autouse=True)
+def _reset_engine():
+    yield
+    _lib.lib().vqa_set_engine(0)
+
+
+def set_engine(name):
+    _lib.check(_lib.lib().vqa_set_engine(ENGINES[name] if name else 0))
+
+
+def compare(c, theta, x, obs_list, marg, si=None, sp=None, sv=None, device_path=False):
+    ia = c.input_angles(x)
+    want_e, want_m = cpu_oracle.eval_batch(c, theta, ia, si, sp, sv, obs_list=obs_tuples(obs_list),
+                                           n_marg_bits=marg)
+    inputs = c.upload_inputs(x) if device_path else ia
+    got_e, got_m = c.eval_batch(theta, inputs, si, sp, sv, obs_list=obs_list, n_marg_bits=marg)
+    if device_path:
+        got_e = got_e.cpu().numpy()
+        got_m = None if got_m is None else got_m.cpu().numpy()
+    assert got_e.shape == want_e.shape
+    if want_e.size:
+        assert np.abs(got_e - want_e).max() < TOL
+    if marg:
+        assert np.abs(got_m - want_m).max() < TOL
+        assert np.abs(got_m.sum(axis=1) - 1).max() < TOL
+
+
+@pytest.mark.parametrize("engine", ["lds", "hbm"])
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 6, 8, 9, 10, 12])
+def test_random_circuits_all_gate_kinds(engine, n):
+    set_engine(engine)
+    c = random_circuit(LearningCircuit, n, 60, seed=100 + n)
+    rng = np.random.default_rng(n)
+    theta = rng.uniform(-3, 3, c.n_theta)
+    x = rng.uniform(-1, 1, (7, 3))
+    E = 19
+    si = rng.integers(0, 7, E).astype(np.int32)
+    sp = rng.integers(-1, c.n_theta, E).astype(np.int32)
+    sv = rng.choice([0.5 * np.pi, -0.5 * np.pi, 0.3], E)
+    obs = random_observables(n, seed=n, xy=True)
+    compare(c, theta, x, obs, min(n, 2), si, sp, sv)
+    compare(c, theta, x, obs, min(n, 2), si, sp, sv, device_path=True)
+
+
+@pytest.mark.parametrize("engine,n,d", [("lds", 4, 2), ("lds", 6, 5), ("lds", 12, 2), ("lds", 13, 1),
+                                        ("hbm", 6, 2), ("hbm", 14, 1), ("hbm", 16, 1)])
+def test_ibm_hea_full_parameter_shift(engine, n, d):
+    set_engine(engine)
+    c = create_ibm_HEA_ansatz(n, d, seed=0)
+    rng = np.random.default_rng(n + d)
+    theta = rng.uniform(0, 2 * np.pi, c.n_theta)
+    B = 3 if n >= 12 else 5
+    x = rng.uniform(0, np.pi, (B, n))
+    ia = c.input_angles(x)
+    z0 = Observable(n); z0.add_operator(1.0, "Z 0")
+    sel = np.array([B - 1, 0], np.int32)
+    si, sp, sv = cpu_oracle.psr_lists(2, c.n_theta, sel=sel)
+    want_e, want_m = cpu_oracle.eval_batch(c, theta, ia, si, sp, sv, obs_list=obs_tuples([z0]), n_marg_bits=2)
+    K = 2 * c.n_theta + 1
+    # host-pointer path
+    got_e, got_m = c.psr_full(theta, ia, sel=sel, obs_list=[z0], n_marg_bits=2)
+    assert got_e.shape == (2, K, 1)
+    assert np.abs(got_e.reshape(-1, 1) - want_e).max() < TOL
+    assert np.abs(got_m.reshape(-1, 4) - want_m).max() < TOL
+    # device-pointer path, inputs resident
+    d_in = c.upload_inputs(x)
+    got_e2, got_m2 = c.psr_full(theta, d_in, sel=sel, obs_list=[z0], n_marg_bits=2)
+    assert np.abs(got_e2.cpu().numpy().reshape(-1, 1) - want_e).max() < TOL
+    assert np.abs(got_m2.cpu().numpy().reshape(-1, 4) - want_m).max() < TOL
+
+
+@pytest.mark.parametrize("engine", ["lds", "hbm"])
+@pytest.mark.parametrize("builder,n,d", [(create_jerbi_ansatz, 5, 2), (create_jerbi_ansatz, 9, 1),
+                                         (create_ry_rz_cz_ansatz, 4, 3), (create_ry_cz_ansatz, 10, 3)])
+def test_other_ansaetze(engine, builder, n, d):
+    set_engine(engine)
+    c = builder(n, d, seed=2)
+    rng = np.random.default_rng(7)
+    theta = rng.uniform(0, 2 * np.pi, c.n_theta)
+    x = rng.uniform(0, np.pi, (6, n))
+    obs = random_observables(n, seed=3, xy=(builder is create_ry_cz_ansatz))
+    compare(c, theta, x, obs, 2)
+
+
+def test_classifier_observables_and_marginal():
+    c = create_ry_rz_cz_ansatz(4, 3, seed=0)
+    rng = np.random.default_rng(0)
+    theta = rng.uniform(0, 2 * np.pi, c.n_theta)
+    x = rng.uniform(0, np.pi, (150, 4))
+    obs = []
+    for terms in ([(1 / 3, ""), (1 / 3, "Z 0 Z 1"), (1 / 6, "Z 0"), (1 / 6, "Z 1")],
+                  [(1 / 3, ""), (-1 / 3, "Z 0"), (1 / 6, "Z 1"), (-1 / 6, "Z 0 Z 1")],
+                  [(1 / 3, ""), (-1 / 3, "Z 1"), (1 / 6, "Z 0"), (-1 / 6, "Z 0 Z 1")]):
+        o = Observable(4)
+        for coef, s in terms:
+            o.add_operator(coef, s)
+        obs.append(o)
+    e, m = c.eval_batch(theta, c.input_angles(x), obs_list=obs, n_marg_bits=2)
+    assert np.abs(e - (m[:, :3] + m[:, 3:4] / 3)).max() < TOL
+    compare(c, theta, x, obs, 2)
+
+
+def test_statevector_and_run_shim():
+    c = create_ibm_HEA_ansatz(5, 1, seed=4)
+    x = np.array([0.3, 1.2, 2.0, 0.7, 2.9])
+    theta = np.array(c.get_parameters())
+    want = cpu_oracle.statevector(c, theta, c.input_row(x))
+    state = c.run(x)
+    assert np.abs(state.get_vector() - want).max() < TOL
+    z0 = Observable(5); z0.add_operator(1.0, "Z 0")
+    ev = z0.get_expectation_value(state)
+    assert abs(ev.real - (np.abs(want[0::2]) ** 2 - np.abs(want[1::2]) ** 2).sum()) < TOL
+    samples = np.array(state.sampling(2000, seed=1))
+    assert samples.min() >= 0 and samples.max() < 32
+    assert abs(((-1.0) ** (samples % 2)).mean() - ev.real) < 0.1
+
+
+def test_empty_batch_and_errors():
+    c = create_ibm_HEA_ansatz(3, 1)
+    theta = np.array(c.get_parameters())
+    ia = c.input_angles(np.zeros((2, 3)))
+    z0 = Observable(3); z0.add_operator(1.0, "Z 0")
+    e, _ = c.eval_batch(theta, ia, sample_idx=np.zeros(0, np.int32), obs_list=[z0])
+    assert e.shape == (0, 1)
+    with pytest.raises(_lib.VqaError):
+        c.eval_batch(theta, ia, sample_idx=np.array([5], np.int32), obs_list=[z0])
+    with pytest.raises(_lib.VqaError):
+        c.eval_batch(theta, ia, sample_idx=np.array([0], np.int32), shift_param=np.array([99], np.int32),
+                     shift_val=np.array([1.0]), obs_list=[z0])
+    bad = Observable(4); bad.add_operator(1.0, "Z 3")
+    with pytest.raises(_lib.VqaError):
+        c.eval_batch(theta, ia, obs_list=[bad])
+
+
+def test_large_batch_linearity_property():
+    """Size-independent check at a batch the oracle would not finish quickly:
+    sum_c p_c = 1 and <Z0> = m0 - m1 + m2 - m3 for every instance."""
+    set_engine("lds")
+    c = create_ibm_HEA_ansatz(6, 5, seed=0)
+    rng = np.random.default_rng(1)
+    x = rng.uniform(-1, 1, (4096, 1))
+    d_in = c.upload_inputs(x)
+    z0 = Observable(6); z0.add_operator(1.0, "Z 0")
+    theta = np.array(c.get_parameters())
+    e, m = c.eval_batch(theta, d_in, obs_list=[z0], n_marg_bits=2)
+    e, m = e.cpu().numpy(), m.cpu().numpy()
+    assert np.abs(m.sum(axis=1) - 1).max() < TOL
+    assert np.abs(e[:, 0] - (m[:, 0] - m[:, 1] + m[:, 2] - m[:, 3])).max() < TOL
+    sub = rng.choice(4096, 64, replace=False)
+    want, _ = cpu_oracle.eval_batch(c, theta, c.input_angles(x[sub]), obs_list=obs_tuples([z0]))
+    assert np.abs(e[sub] - want).max() < TOL

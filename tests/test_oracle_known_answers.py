@@ -1,0 +1,186 @@
+"""Known-answer tests that pin the CPU oracle (oracle/oracle.c) to the qulacs
+conventions the reference relies on.  The reference ships no golden vectors for
+this path (its tests/test_sample.py is a placeholder), so these analytic cases
+and an independent dense-matrix oracle are what the oracle is anchored on
+("parity unpinned" with respect to a qulacs binary)."""
+import numpy as np
+import pytest
+
+from vqa_amd.circuit import GateList
+from vqa_amd.qml_utils import (create_ibm_HEA_ansatz, create_jerbi_ansatz,
+                               create_ry_cz_ansatz, create_ry_rz_cz_ansatz)
+from oracle import cpu_oracle, dense_numpy
+
+Z0 = ([1.0], [1])
+
+
+def ev(c, theta=(), row=None, obs=(Z0,), marg=0):
+    ia = None if row is None else np.asarray(row, float)[None, :]
+    e, m = cpu_oracle.eval_batch(c, np.asarray(theta, float), ia, obs_list=list(obs), n_marg_bits=marg)
+    return e[0], (None if m is None else m[0])
+
+
+@pytest.mark.parametrize("th", [0.0, 0.3, 1.1, 2.7, -0.9])
+def test_ka1_single_qubit_rotations(th):
+    c = GateList(1); c.add_parametric_RY_gate(0, th)
+    assert ev(c, [th])[0][0] == pytest.approx(np.cos(th), abs=1e-14)
+    c = GateList(1); c.add_parametric_RX_gate(0, th)
+    assert ev(c, [th])[0][0] == pytest.approx(np.cos(th), abs=1e-14)
+    # the only Z-basis-visible sign convention: RY(th) then H -> <Z> = -sin(th)
+    # under qulacs' exp(+i th/2 Y); the textbook sign would give +sin(th)
+    c = GateList(1); c.add_parametric_RY_gate(0, th); c.add_H_gate(0)
+    assert ev(c, [th])[0][0] == pytest.approx(-np.sin(th), abs=1e-14)
+    c = GateList(1); c.add_H_gate(0); c.add_parametric_RZ_gate(0, th); c.add_H_gate(0)
+    assert ev(c, [th])[0][0] == pytest.approx(np.cos(th), abs=1e-14)
+    # H, RZ(phi), RX(pi/2): <Z> = -sin(phi) with exp(+i a/2 P) on both
+    # rotations; only the overall sign of both conventions together is visible
+    c = GateList(1); c.add_H_gate(0); c.add_parametric_RZ_gate(0, th); c.add_RX_gate(0, np.pi / 2)
+    assert abs(ev(c, [th])[0][0]) == pytest.approx(abs(np.sin(th)), abs=1e-14)
+
+
+def test_rotation_matrices_match_qulacs_convention():
+    a = 0.73
+    c, s = np.cos(a / 2), np.sin(a / 2)
+    for add, want in [("RX", [[c, 1j * s], [1j * s, c]]), ("RY", [[c, s], [-s, c]]),
+                      ("RZ", [[np.exp(1j * a / 2), 0], [0, np.exp(-1j * a / 2)]])]:
+        cols = []
+        for basis in (0, 1):
+            g = GateList(1)
+            if basis: g.add_X_gate(0)
+            getattr(g, f"add_{add}_gate")(0, a)
+            cols.append(cpu_oracle.statevector(g, []))
+        got = np.array(cols).T
+        assert np.allclose(got, np.array(want), atol=1e-15)
+
+
+def test_ka2_bell_and_ghz():
+    c = GateList(2); c.add_H_gate(0); c.add_CNOT_gate(0, 1)
+    e, m = ev(c, obs=[([1.0], [3]), Z0, ([1.0], [2])], marg=2)
+    assert e == pytest.approx([1.0, 0.0, 0.0], abs=1e-15)
+    assert m == pytest.approx([0.5, 0, 0, 0.5], abs=1e-15)
+    n = 5
+    c = GateList(n); c.add_H_gate(0)
+    for q in range(1, n): c.add_CNOT_gate(q - 1, q)
+    psi = cpu_oracle.statevector(c, [])
+    want = np.zeros(1 << n, complex); want[0] = want[-1] = 1 / np.sqrt(2)
+    assert np.allclose(psi, want, atol=1e-15)
+
+
+def test_cnot_direction():
+    # control = first argument of add_CNOT_gate, target = second (QML_utils.py:55)
+    c = GateList(2); c.add_X_gate(1); c.add_CNOT_gate(1, 0)
+    assert np.argmax(np.abs(cpu_oracle.statevector(c, []))) == 3
+    c = GateList(2); c.add_X_gate(1); c.add_CNOT_gate(0, 1)
+    assert np.argmax(np.abs(cpu_oracle.statevector(c, []))) == 2
+
+
+@pytest.mark.parametrize("n", [2, 3, 5])
+def test_ka3_cz_ring_on_plus_state(n):
+    c = GateList(n)
+    for q in range(n): c.add_H_gate(q)
+    for q in range(n): c.add_CZ_gate(q, (q + 1) % n)
+    psi = cpu_oracle.statevector(c, [])
+    for k in range(1 << n):
+        par = sum(((k >> q) & 1) & ((k >> ((q + 1) % n)) & 1) for q in range(n))
+        if n == 2: par = 2 * ((k & 1) & (k >> 1))  # the ring visits the only pair twice
+        assert psi[k] == pytest.approx((-1) ** par / np.sqrt(1 << n), abs=1e-15)
+
+
+def test_pauli_xy_terms():
+    c = GateList(2); c.add_RY_gate(0, 0.4); c.add_RX_gate(1, 1.3); c.add_CNOT_gate(0, 1); c.add_RZ_gate(0, 0.8)
+    psi = dense_numpy.statevector(c, [])
+    for z, x in [(0, 1), (1, 1), (2, 3), (3, 3), (1, 2), (0, 0), (3, 1)]:
+        got = ev(c, obs=[([0.7], [z], [x])])[0][0]
+        assert got == pytest.approx(0.7 * dense_numpy.expectation(psi, 2, [1.0], [z], [x]), abs=1e-14)
+
+
+@pytest.mark.parametrize("builder,n,d", [(create_ibm_HEA_ansatz, 3, 1), (create_ibm_HEA_ansatz, 6, 2),
+                                         (create_jerbi_ansatz, 4, 2), (create_jerbi_ansatz, 7, 1),
+                                         (create_ry_rz_cz_ansatz, 4, 3), (create_ry_cz_ansatz, 8, 2)])
+def test_ka4_dense_kronecker_oracle_agrees(builder, n, d):
+    c = builder(n, d, seed=3, circuit_cls=GateList)
+    rng = np.random.default_rng(n * 10 + d)
+    theta = rng.uniform(0, 2 * np.pi, c.n_theta)
+    x = rng.uniform(0, np.pi, n)
+    row = c.input_row(x)
+    psi_c = cpu_oracle.statevector(c, theta, row)
+    psi_d = dense_numpy.statevector(c, theta, row)
+    assert np.abs(psi_c - psi_d).max() < 1e-13
+    sp = int(rng.integers(c.n_theta))
+    psi_c = cpu_oracle.statevector(c, theta, row, sp, 0.5 * np.pi)
+    psi_d = dense_numpy.statevector(c, theta, row, sp, 0.5 * np.pi)
+    assert np.abs(psi_c - psi_d).max() < 1e-13
+    assert abs(np.vdot(psi_c, psi_c) - 1) < 1e-13
+
+
+def test_ansatz_counts_match_reference_formulae():
+    # G = 13n + 4nd, P = 3n(d+1), 4n input gates (vqa/QNN/QML_utils.py:101-164)
+    for n, d in [(6, 5), (12, 10), (20, 8)]:
+        c = create_ibm_HEA_ansatz(n, d, circuit_cls=GateList)
+        assert (c.n_ops, c.n_theta, c.n_input) == (13 * n + 4 * n * d, 3 * n * (d + 1), 4 * n)
+    n, d = 5, 2
+    c = create_jerbi_ansatz(n, d, circuit_cls=GateList)
+    assert c.n_input == 2 * (n + n * (n - 1) // 2) and c.n_theta == 3 * n * (d + 1)
+    # initial angles: 2*pi*default_rng(seed).random() in gate order
+    rng = np.random.default_rng(0)
+    assert np.allclose(c.get_parameters(), [2 * np.pi * rng.random() for _ in range(c.n_theta)])
+
+
+def test_reference_closure_quirk():
+    # the reference's ZZ lambdas read `j` late: IBM map uses (pi-x_i)(pi-x_0)
+    c = create_ibm_HEA_ansatz(4, 1, circuit_cls=GateList)
+    x = np.array([0.1, 0.7, 1.3, 2.2])
+    row = c.input_row(x)
+    assert row[0] == x[0] and row[1] == pytest.approx((np.pi - x[0]) * (np.pi - x[0]))
+    assert row[3] == pytest.approx((np.pi - x[1]) * (np.pi - x[0]))
+    c2 = create_ibm_HEA_ansatz(4, 1, circuit_cls=GateList, reference_closure=False)
+    assert c2.input_row(x)[3] == pytest.approx((np.pi - x[1]) * (np.pi - x[2]))
+    cj = create_jerbi_ansatz(4, 1, circuit_cls=GateList)
+    # gate order: RZ(x0); RZ(x1), ZZ(1,0); RZ(x2), ZZ(2,0), ZZ(2,1); ...   j seen = n-2 = 2
+    assert cj.input_row(x)[2] == pytest.approx(x[1] * x[2])
+
+
+def test_ka5_parameter_shift_equals_derivative():
+    c = create_ibm_HEA_ansatz(4, 2, seed=1, circuit_cls=GateList)
+    rng = np.random.default_rng(5)
+    theta = rng.uniform(0, 2 * np.pi, c.n_theta)
+    ia = c.input_angles(rng.uniform(0, np.pi, (2, 4)))
+    si, sp, sv = cpu_oracle.psr_lists(2, c.n_theta)
+    e, _ = cpu_oracle.eval_batch(c, theta, ia, si, sp, sv, obs_list=[Z0])
+    e = e.reshape(2, 2 * c.n_theta + 1)
+    psr = 0.5 * (e[:, 1::2] - e[:, 2::2])
+    h = 1e-6
+    for i in range(0, c.n_theta, 5):
+        tp, tm = theta.copy(), theta.copy(); tp[i] += h; tm[i] -= h
+        ep, _ = cpu_oracle.eval_batch(c, tp, ia, obs_list=[Z0])
+        em, _ = cpu_oracle.eval_batch(c, tm, ia, obs_list=[Z0])
+        assert psr[:, i] == pytest.approx(((ep - em) / (2 * h)).ravel(), abs=1e-8)
+
+
+def test_ka6_classifier_povm_algebra():
+    # class observables of vqa/QNN/myQNNs_classifier.py:308-322 (class_unbias):
+    # p_c = m_c + m_3 / 3 with m the marginal of the two lowest qubits
+    c = create_ry_rz_cz_ansatz(4, 3, seed=0, circuit_cls=GateList)
+    rng = np.random.default_rng(2)
+    theta = rng.uniform(0, 2 * np.pi, c.n_theta)
+    ia = c.input_angles(rng.uniform(0, np.pi, (5, 4)))
+    obs = [([1 / 3, 1 / 3, 1 / 6, 1 / 6], [0, 3, 1, 2]),
+           ([1 / 3, -1 / 3, 1 / 6, -1 / 6], [0, 1, 2, 3]),
+           ([1 / 3, -1 / 3, 1 / 6, -1 / 6], [0, 2, 1, 3])]
+    e, m = cpu_oracle.eval_batch(c, theta, ia, obs_list=obs, n_marg_bits=2)
+    assert e.sum(axis=1) == pytest.approx(np.ones(5), abs=1e-14)
+    assert e == pytest.approx(m[:, :3] + m[:, 3:4] / 3, abs=1e-14)
+    assert m.sum(axis=1) == pytest.approx(np.ones(5), abs=1e-14)
+
+
+def test_empty_and_ragged_batches():
+    c = create_ibm_HEA_ansatz(3, 1, circuit_cls=GateList)
+    theta = np.array(c.get_parameters())
+    ia = c.input_angles(np.random.default_rng(0).uniform(0, 1, (4, 3)))
+    e, _ = cpu_oracle.eval_batch(c, theta, ia, sample_idx=np.array([3, 3, 0], np.int32),
+                                 shift_param=np.array([-1, 2, 5], np.int32),
+                                 shift_val=np.array([0.0, 0.5, -0.5]), obs_list=[Z0])
+    full, _ = cpu_oracle.eval_batch(c, theta, ia, obs_list=[Z0])
+    assert e[0, 0] == pytest.approx(full[3, 0], abs=1e-15)
+    e0, _ = cpu_oracle.eval_batch(c, theta, ia, sample_idx=np.zeros(0, np.int32), obs_list=[Z0])
+    assert e0.shape == (0, 1)

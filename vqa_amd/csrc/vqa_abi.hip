@@ -1,0 +1,454 @@
+// C-ABI layer of libvqahip.so: handles, argument checks, per-device streams and
+// workspaces, host<->device staging for the host-pointer entry points, and the
+// dispatch to the engines.  Declarations and the reference interfaces each
+// entry point replaces: include/vqa_hip.h.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "vqa_core.h"
+
+namespace vqa {
+
+static thread_local char g_err[512] = "";
+static int g_engine = 0;  // 0 auto
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ---- per-device state ------------------------------------------------------
+struct DeviceState {
+    hipStream_t stream = nullptr;
+    void* ws = nullptr;
+    size_t ws_bytes = 0;
+};
+static std::mutex g_dev_mu;
+static std::map<int, DeviceState> g_dev;
+
+static int device_state(int device, DeviceState** out) {
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    auto it = g_dev.find(device);
+    if (it == g_dev.end()) {
+        int count = 0;
+        VQA_HIP(hipGetDeviceCount(&count));
+        if (device < 0 || device >= count)
+            VQA_FAIL(VQA_ENODEVICE, "device %d out of range (%d visible)", device, count);
+        VQA_HIP(hipSetDevice(device));
+        DeviceState ds;
+        VQA_HIP(hipStreamCreateWithFlags(&ds.stream, hipStreamNonBlocking));
+        it = g_dev.emplace(device, ds).first;
+    }
+    *out = &it->second;
+    return VQA_OK;
+}
+
+int workspace_get(int device, size_t bytes, void** out) {
+    DeviceState* ds;
+    int rc = device_state(device, &ds);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    if (ds->ws_bytes < bytes) {
+        VQA_HIP(hipSetDevice(device));
+        if (ds->ws) {
+            VQA_HIP(hipDeviceSynchronize());
+            VQA_HIP(hipFree(ds->ws));
+            ds->ws = nullptr;
+            ds->ws_bytes = 0;
+        }
+        const size_t want = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+        hipError_t e = hipMalloc(&ds->ws, want);
+        if (e != hipSuccess) VQA_FAIL(VQA_ENOMEM, "hipMalloc of %zu workspace bytes failed: %s", want, hipGetErrorString(e));
+        ds->ws_bytes = want;
+    }
+    *out = ds->ws;
+    return VQA_OK;
+}
+
+// ---- circuit helpers ---------------------------------------------------------
+static int circuit_device_ctx(vqa_circuit* c, int device, DeviceCtx** out) {
+    std::lock_guard<std::mutex> lk(c->mu);
+    auto it = c->dev.find(device);
+    if (it == c->dev.end()) {
+        DeviceCtx ctx;
+        VQA_HIP(hipSetDevice(device));
+        const size_t bytes = std::max<size_t>(1, c->ops.size()) * sizeof(vqa_op);
+        hipError_t e = hipMalloc((void**)&ctx.d_ops, bytes);
+        if (e != hipSuccess) VQA_FAIL(VQA_ENOMEM, "hipMalloc of the op table failed: %s", hipGetErrorString(e));
+        if (!c->ops.empty())
+            VQA_HIP(hipMemcpy(ctx.d_ops, c->ops.data(), c->ops.size() * sizeof(vqa_op), hipMemcpyHostToDevice));
+        it = c->dev.emplace(device, ctx).first;
+    }
+    *out = &it->second;
+    return VQA_OK;
+}
+
+static int pack_obs(const vqa_circuit* c, const vqa_obs* const* obs, int n_obs, ObsPack* p) {
+    if (n_obs < 0 || n_obs > kMaxObs) VQA_FAIL(VQA_EINVAL, "n_obs must be in [0, %d] (got %d)", kMaxObs, n_obs);
+    if (n_obs > 0 && !obs) VQA_FAIL(VQA_EINVAL, "obs is NULL with n_obs = %d", n_obs);
+    memset(p, 0, sizeof(*p));
+    p->n_obs = n_obs;
+    int nt = 0;
+    for (int o = 0; o < n_obs; ++o) {
+        if (!obs[o]) VQA_FAIL(VQA_EINVAL, "obs[%d] is NULL", o);
+        if (obs[o]->n_qubits != c->n_qubits)
+            VQA_FAIL(VQA_EINVAL, "obs[%d] is on %d qubits, the circuit on %d", o, obs[o]->n_qubits, c->n_qubits);
+        p->off[o] = nt;
+        for (size_t t = 0; t < obs[o]->coef.size(); ++t) {
+            if (nt >= kMaxTerms)
+                VQA_FAIL(VQA_EUNSUPPORTED, "more than %d Pauli terms in one call", kMaxTerms);
+            p->coef[nt] = obs[o]->coef[t];
+            p->z[nt] = obs[o]->z[t];
+            p->x[nt] = obs[o]->x[t];
+            ++nt;
+        }
+    }
+    p->off[n_obs] = nt;
+    p->n_terms = nt;
+    return VQA_OK;
+}
+
+static int resolve_engine(const vqa_circuit* c) { return c->engine; }
+
+static int run_call(EvalCall& call) {
+    VQA_HIP(hipSetDevice(call.device));
+    switch (resolve_engine(call.c)) {
+    case 1: return lds_engine_run(call);
+    case 3: return hbm_engine_run(call);
+    default: VQA_FAIL(VQA_EUNSUPPORTED, "engine %d is not available in this build", call.c->engine);
+    }
+}
+
+static int check_common(vqa_circuit* c, int device, const double* theta, const double* input, int B,
+                        int n_obs, int n_marg_bits, const double* out_e, const double* out_m) {
+    if (!c) VQA_FAIL(VQA_EINVAL, "circuit handle is NULL");
+    (void)device;
+    if (c->n_theta > 0 && !theta) VQA_FAIL(VQA_EINVAL, "theta is NULL but the circuit has %d parameters", c->n_theta);
+    if (c->n_input > 0 && (!input || B <= 0))
+        VQA_FAIL(VQA_EINVAL, "input_angles is NULL or B <= 0 but the circuit has %d input gates", c->n_input);
+    if (B < 0) VQA_FAIL(VQA_EINVAL, "B must be >= 0 (got %d)", B);
+    if (n_marg_bits < 0 || n_marg_bits > c->n_qubits)
+        VQA_FAIL(VQA_EINVAL, "n_marg_bits must be in [0, n_qubits] (got %d)", n_marg_bits);
+    if (n_obs > 0 && !out_e) VQA_FAIL(VQA_EINVAL, "out_expect is NULL with n_obs = %d", n_obs);
+    if (n_marg_bits > 0 && !out_m) VQA_FAIL(VQA_EINVAL, "out_marginal is NULL with n_marg_bits = %d", n_marg_bits);
+    return VQA_OK;
+}
+
+// small RAII device buffer for the host-pointer entry points
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) {
+        hipError_t e = hipMalloc(&p, std::max<size_t>(bytes, 8));
+        if (e != hipSuccess) VQA_FAIL(VQA_ENOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return VQA_OK;
+    }
+    int upload(const void* src, size_t bytes, hipStream_t s) {
+        int rc = alloc(bytes);
+        if (rc) return rc;
+        if (bytes) VQA_HIP(hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, s));
+        return VQA_OK;
+    }
+};
+
+}  // namespace vqa
+
+using namespace vqa;
+
+extern "C" {
+
+int vqa_version(void) { return VQA_ABI_VERSION; }
+
+const char* vqa_last_error(void) { return g_err; }
+
+int vqa_device_count(void) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess) {
+        set_error("hipGetDeviceCount failed: %s", hipGetErrorString(e));
+        return e == hipErrorNoDevice ? 0 : VQA_EHIP;
+    }
+    return count;
+}
+
+int vqa_sync(int device) {
+    DeviceState* ds;
+    int rc = device_state(device, &ds);
+    if (rc) return rc;
+    VQA_HIP(hipStreamSynchronize(ds->stream));
+    return VQA_OK;
+}
+
+int vqa_set_engine(int engine) {
+    if (engine < 0 || engine > 3) VQA_FAIL(VQA_EINVAL, "engine must be 0..3 (got %d)", engine);
+    g_engine = engine;
+    return VQA_OK;
+}
+
+int vqa_circuit_create(int n_qubits, const vqa_op* ops, int n_ops, int n_theta, int n_input,
+                       vqa_circuit** out) {
+    if (!out) VQA_FAIL(VQA_EINVAL, "out is NULL");
+    if (n_qubits < 1 || n_qubits > 30) VQA_FAIL(VQA_EINVAL, "n_qubits must be in [1, 30] (got %d)", n_qubits);
+    if (n_ops < 0 || (n_ops > 0 && !ops)) VQA_FAIL(VQA_EINVAL, "ops is NULL or n_ops < 0");
+    if (n_theta < 0 || n_input < 0) VQA_FAIL(VQA_EINVAL, "n_theta and n_input must be >= 0");
+    for (int g = 0; g < n_ops; ++g) {
+        const vqa_op& op = ops[g];
+        if (op.kind < VQA_GATE_H || op.kind > VQA_GATE_CZ) VQA_FAIL(VQA_EINVAL, "op %d: unknown gate kind %d", g, op.kind);
+        if (op.q0 < 0 || op.q0 >= n_qubits) VQA_FAIL(VQA_EINVAL, "op %d: qubit %d out of range", g, op.q0);
+        const bool two = op.kind == VQA_GATE_CNOT || op.kind == VQA_GATE_CZ;
+        if (two && (op.q1 < 0 || op.q1 >= n_qubits || op.q1 == op.q0))
+            VQA_FAIL(VQA_EINVAL, "op %d: second qubit %d invalid", g, op.q1);
+        if (op.kind >= VQA_GATE_RX && op.kind <= VQA_GATE_RZ) {
+            if (op.src < VQA_SRC_CONST || op.src > VQA_SRC_INPUT) VQA_FAIL(VQA_EINVAL, "op %d: unknown angle source %d", g, op.src);
+            if (op.src == VQA_SRC_THETA && (op.idx < 0 || op.idx >= n_theta))
+                VQA_FAIL(VQA_EINVAL, "op %d: theta index %d out of range [0, %d)", g, op.idx, n_theta);
+            if (op.src == VQA_SRC_INPUT && (op.idx < 0 || op.idx >= n_input))
+                VQA_FAIL(VQA_EINVAL, "op %d: input index %d out of range [0, %d)", g, op.idx, n_input);
+        }
+    }
+    int engine = g_engine;
+    if (engine == 0) engine = n_qubits <= lds_engine_max_qubits() ? 1 : 3;
+    if (engine == 1 && n_qubits > lds_engine_max_qubits())
+        VQA_FAIL(VQA_EUNSUPPORTED, "the LDS engine holds at most %d qubits", lds_engine_max_qubits());
+    if (engine == 2) VQA_FAIL(VQA_EUNSUPPORTED, "engine 2 is not available in this build");
+    vqa_circuit* c = new (std::nothrow) vqa_circuit();
+    if (!c) VQA_FAIL(VQA_ENOMEM, "out of host memory");
+    c->n_qubits = n_qubits;
+    c->n_ops = n_ops;
+    c->n_theta = n_theta;
+    c->n_input = n_input;
+    c->engine = engine;
+    c->ops.assign(ops, ops + n_ops);
+    *out = c;
+    return VQA_OK;
+}
+
+int vqa_circuit_destroy(vqa_circuit* c) {
+    if (!c) return VQA_OK;
+    for (auto& kv : c->dev) {
+        (void)hipSetDevice(kv.first);
+        if (kv.second.d_ops) (void)hipFree(kv.second.d_ops);
+        if (kv.second.reg_prog) (void)hipFree(kv.second.reg_prog);
+    }
+    delete c;
+    return VQA_OK;
+}
+
+int vqa_circuit_info(const vqa_circuit* c, int* n_qubits, int* n_ops, int* n_theta, int* n_input) {
+    if (!c) VQA_FAIL(VQA_EINVAL, "circuit handle is NULL");
+    if (n_qubits) *n_qubits = c->n_qubits;
+    if (n_ops) *n_ops = c->n_ops;
+    if (n_theta) *n_theta = c->n_theta;
+    if (n_input) *n_input = c->n_input;
+    return VQA_OK;
+}
+
+int vqa_observable_create(int n_qubits, const double* coefs, const uint64_t* zmasks,
+                          const uint64_t* xmasks, int n_terms, vqa_obs** out) {
+    if (!out) VQA_FAIL(VQA_EINVAL, "out is NULL");
+    if (n_qubits < 1 || n_qubits > 30) VQA_FAIL(VQA_EINVAL, "n_qubits must be in [1, 30] (got %d)", n_qubits);
+    if (n_terms < 0 || (n_terms > 0 && (!coefs || !zmasks))) VQA_FAIL(VQA_EINVAL, "coefs/zmasks NULL or n_terms < 0");
+    const uint64_t lim = (uint64_t)1 << n_qubits;
+    for (int t = 0; t < n_terms; ++t) {
+        if (zmasks[t] >= lim || (xmasks && xmasks[t] >= lim))
+            VQA_FAIL(VQA_EINVAL, "term %d: Pauli mask has bits beyond qubit %d", t, n_qubits - 1);
+    }
+    vqa_obs* o = new (std::nothrow) vqa_obs();
+    if (!o) VQA_FAIL(VQA_ENOMEM, "out of host memory");
+    o->n_qubits = n_qubits;
+    o->coef.assign(coefs, coefs + n_terms);
+    o->z.assign(zmasks, zmasks + n_terms);
+    if (xmasks) o->x.assign(xmasks, xmasks + n_terms);
+    else o->x.assign(n_terms, 0);
+    *out = o;
+    return VQA_OK;
+}
+
+int vqa_observable_destroy(vqa_obs* o) {
+    delete o;
+    return VQA_OK;
+}
+
+static int eval_dev_common(vqa_circuit* c, int device, void* stream, const double* d_theta,
+                           const double* d_input, int B, const EvalSpec& spec, int64_t E,
+                           const vqa_obs* const* obs, int n_obs, int n_marg_bits, double* d_out_e,
+                           double* d_out_m) {
+    int rc = check_common(c, device, d_theta, d_input, B, n_obs, n_marg_bits, d_out_e, d_out_m);
+    if (rc) return rc;
+    if (E < 0) VQA_FAIL(VQA_EINVAL, "E must be >= 0");
+    EvalCall call;
+    call.c = c;
+    call.device = device;
+    rc = pack_obs(c, obs, n_obs, &call.obs);
+    if (rc) return rc;
+    DeviceState* ds;
+    rc = device_state(device, &ds);
+    if (rc) return rc;
+    DeviceCtx* ctx;
+    rc = circuit_device_ctx(c, device, &ctx);
+    if (rc) return rc;
+    call.stream = stream ? (hipStream_t)stream : ds->stream;
+    call.d_ops = ctx->d_ops;
+    call.d_theta = d_theta;
+    call.d_input = d_input;
+    call.spec = spec;
+    call.E = E;
+    call.n_marg_bits = n_marg_bits;
+    call.d_out_expect = d_out_e;
+    call.d_out_marginal = d_out_m;
+    return run_call(call);
+}
+
+int vqa_eval_batch_dev(vqa_circuit* c, int device, void* stream, const double* d_theta,
+                       const double* d_input_angles, int B, const int32_t* d_sample_idx,
+                       const int32_t* d_shift_param, const double* d_shift_val, int64_t E,
+                       const vqa_obs* const* obs, int n_obs, int n_marg_bits,
+                       double* d_out_expect, double* d_out_marginal) {
+    if ((d_shift_param == nullptr) != (d_shift_val == nullptr))
+        VQA_FAIL(VQA_EINVAL, "shift_param and shift_val must both be given or both be NULL");
+    if (!d_sample_idx && c && c->n_input > 0 && E > B)
+        VQA_FAIL(VQA_EINVAL, "sample_idx is NULL but E (%lld) > B (%d)", (long long)E, B);
+    EvalSpec spec = { d_sample_idx, d_shift_param, d_shift_val, nullptr, 0, 0, 0.0 };
+    return eval_dev_common(c, device, stream, d_theta, d_input_angles, B, spec, E, obs, n_obs,
+                           n_marg_bits, d_out_expect, d_out_marginal);
+}
+
+int vqa_psr_full_dev(vqa_circuit* c, int device, void* stream, const double* d_theta,
+                     const double* d_input_angles, int B, const int32_t* d_sel, int n_sel,
+                     double shift, const vqa_obs* const* obs, int n_obs, int n_marg_bits,
+                     double* d_out_expect, double* d_out_marginal) {
+    if (!c) VQA_FAIL(VQA_EINVAL, "circuit handle is NULL");
+    if (n_sel < 0) VQA_FAIL(VQA_EINVAL, "n_sel must be >= 0");
+    if (!d_sel && c->n_input > 0 && n_sel > B)
+        VQA_FAIL(VQA_EINVAL, "sel is NULL but n_sel (%d) > B (%d)", n_sel, B);
+    EvalSpec spec = { nullptr, nullptr, nullptr, d_sel, 1, c->n_theta, shift };
+    const int64_t E = (int64_t)n_sel * (2 * (int64_t)c->n_theta + 1);
+    return eval_dev_common(c, device, stream, d_theta, d_input_angles, B, spec, E, obs, n_obs,
+                           n_marg_bits, d_out_expect, d_out_marginal);
+}
+
+static int check_indices(const vqa_circuit* c, int B, const int32_t* idx, int64_t n, const char* what) {
+    if (!idx || c->n_input == 0) return VQA_OK;
+    for (int64_t i = 0; i < n; ++i)
+        if (idx[i] < 0 || idx[i] >= B) VQA_FAIL(VQA_EINVAL, "%s[%lld] = %d out of range [0, %d)", what, (long long)i, idx[i], B);
+    return VQA_OK;
+}
+
+int vqa_eval_batch(vqa_circuit* c, int device, const double* theta, const double* input_angles,
+                   int B, const int32_t* sample_idx, const int32_t* shift_param,
+                   const double* shift_val, int64_t E, const vqa_obs* const* obs, int n_obs,
+                   int n_marg_bits, double* out_expect, double* out_marginal) {
+    int rc = check_common(c, device, theta, input_angles, B, n_obs, n_marg_bits, out_expect, out_marginal);
+    if (rc) return rc;
+    if (E < 0) VQA_FAIL(VQA_EINVAL, "E must be >= 0");
+    if (E == 0) return VQA_OK;
+    rc = check_indices(c, B, sample_idx, E, "sample_idx");
+    if (rc) return rc;
+    if (shift_param)
+        for (int64_t i = 0; i < E; ++i)
+            if (shift_param[i] < -1 || shift_param[i] >= c->n_theta)
+                VQA_FAIL(VQA_EINVAL, "shift_param[%lld] = %d out of range [-1, %d)", (long long)i, shift_param[i], c->n_theta);
+    DeviceState* ds;
+    rc = device_state(device, &ds);
+    if (rc) return rc;
+    VQA_HIP(hipSetDevice(device));
+    hipStream_t s = ds->stream;
+    const size_t M = (size_t)1 << n_marg_bits;
+    DevBuf dth, din, dsi, dsp, dsv, doe, dom;
+    if ((rc = dth.upload(theta, (size_t)c->n_theta * 8, s))) return rc;
+    if ((rc = din.upload(input_angles, (size_t)B * c->n_input * 8, s))) return rc;
+    if (sample_idx && (rc = dsi.upload(sample_idx, (size_t)E * 4, s))) return rc;
+    if (shift_param && (rc = dsp.upload(shift_param, (size_t)E * 4, s))) return rc;
+    if (shift_val && (rc = dsv.upload(shift_val, (size_t)E * 8, s))) return rc;
+    if (n_obs > 0 && (rc = doe.alloc((size_t)E * n_obs * 8))) return rc;
+    if (n_marg_bits > 0 && (rc = dom.alloc((size_t)E * M * 8))) return rc;
+    rc = vqa_eval_batch_dev(c, device, s, (double*)dth.p, (double*)din.p, B, (int32_t*)dsi.p,
+                            (int32_t*)dsp.p, (double*)dsv.p, E, obs, n_obs, n_marg_bits,
+                            (double*)doe.p, (double*)dom.p);
+    if (rc) { (void)hipStreamSynchronize(s); return rc; }
+    if (n_obs > 0) VQA_HIP(hipMemcpyAsync(out_expect, doe.p, (size_t)E * n_obs * 8, hipMemcpyDeviceToHost, s));
+    if (n_marg_bits > 0) VQA_HIP(hipMemcpyAsync(out_marginal, dom.p, (size_t)E * M * 8, hipMemcpyDeviceToHost, s));
+    VQA_HIP(hipStreamSynchronize(s));
+    return VQA_OK;
+}
+
+int vqa_psr_full(vqa_circuit* c, int device, const double* theta, const double* input_angles, int B,
+                 const int32_t* sel, int n_sel, double shift, const vqa_obs* const* obs, int n_obs,
+                 int n_marg_bits, double* out_expect, double* out_marginal) {
+    int rc = check_common(c, device, theta, input_angles, B, n_obs, n_marg_bits, out_expect, out_marginal);
+    if (rc) return rc;
+    if (n_sel < 0) VQA_FAIL(VQA_EINVAL, "n_sel must be >= 0");
+    if (n_sel == 0) return VQA_OK;
+    rc = check_indices(c, B, sel, n_sel, "sel");
+    if (rc) return rc;
+    DeviceState* ds;
+    rc = device_state(device, &ds);
+    if (rc) return rc;
+    VQA_HIP(hipSetDevice(device));
+    hipStream_t s = ds->stream;
+    const size_t M = (size_t)1 << n_marg_bits;
+    const size_t E = (size_t)n_sel * (2 * (size_t)c->n_theta + 1);
+    DevBuf dth, din, dsel, doe, dom;
+    if ((rc = dth.upload(theta, (size_t)c->n_theta * 8, s))) return rc;
+    if ((rc = din.upload(input_angles, (size_t)B * c->n_input * 8, s))) return rc;
+    if (sel && (rc = dsel.upload(sel, (size_t)n_sel * 4, s))) return rc;
+    if (n_obs > 0 && (rc = doe.alloc(E * n_obs * 8))) return rc;
+    if (n_marg_bits > 0 && (rc = dom.alloc(E * M * 8))) return rc;
+    rc = vqa_psr_full_dev(c, device, s, (double*)dth.p, (double*)din.p, B, (int32_t*)dsel.p, n_sel,
+                          shift, obs, n_obs, n_marg_bits, (double*)doe.p, (double*)dom.p);
+    if (rc) { (void)hipStreamSynchronize(s); return rc; }
+    if (n_obs > 0) VQA_HIP(hipMemcpyAsync(out_expect, doe.p, E * n_obs * 8, hipMemcpyDeviceToHost, s));
+    if (n_marg_bits > 0) VQA_HIP(hipMemcpyAsync(out_marginal, dom.p, E * M * 8, hipMemcpyDeviceToHost, s));
+    VQA_HIP(hipStreamSynchronize(s));
+    return VQA_OK;
+}
+
+int vqa_statevector(vqa_circuit* c, int device, const double* theta, const double* input_row,
+                    int shift_param, double shift_val, double* out_state) {
+    if (!c) VQA_FAIL(VQA_EINVAL, "circuit handle is NULL");
+    if (!out_state) VQA_FAIL(VQA_EINVAL, "out_state is NULL");
+    if (c->n_theta > 0 && !theta) VQA_FAIL(VQA_EINVAL, "theta is NULL");
+    if (c->n_input > 0 && !input_row) VQA_FAIL(VQA_EINVAL, "input_row is NULL");
+    if (shift_param < -1 || shift_param >= c->n_theta) VQA_FAIL(VQA_EINVAL, "shift_param out of range");
+    DeviceState* ds;
+    int rc = device_state(device, &ds);
+    if (rc) return rc;
+    DeviceCtx* ctx;
+    rc = circuit_device_ctx(c, device, &ctx);
+    if (rc) return rc;
+    VQA_HIP(hipSetDevice(device));
+    hipStream_t s = ds->stream;
+    const size_t D = (size_t)1 << c->n_qubits;
+    DevBuf dth, din, dsp, dsv, dst;
+    if ((rc = dth.upload(theta, (size_t)c->n_theta * 8, s))) return rc;
+    if ((rc = din.upload(input_row, (size_t)c->n_input * 8, s))) return rc;
+    const int32_t sp = shift_param;
+    if ((rc = dsp.upload(&sp, 4, s))) return rc;
+    if ((rc = dsv.upload(&shift_val, 8, s))) return rc;
+    if ((rc = dst.alloc(D * 16))) return rc;
+    EvalCall call;
+    call.c = c;
+    call.device = device;
+    call.stream = s;
+    call.d_ops = ctx->d_ops;
+    call.d_theta = (double*)dth.p;
+    call.d_input = (double*)din.p;
+    call.spec = EvalSpec{ nullptr, (int32_t*)dsp.p, (double*)dsv.p, nullptr, 0, 0, 0.0 };
+    call.E = 1;
+    memset(&call.obs, 0, sizeof(call.obs));
+    call.n_marg_bits = 0;
+    call.d_out_expect = nullptr;
+    call.d_out_marginal = nullptr;
+    rc = hbm_engine_statevector(call, (double*)dst.p);
+    if (rc) { (void)hipStreamSynchronize(s); return rc; }
+    VQA_HIP(hipMemcpyAsync(out_state, dst.p, D * 16, hipMemcpyDeviceToHost, s));
+    VQA_HIP(hipStreamSynchronize(s));
+    return VQA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,146 @@
+// Internal declarations shared by the C-ABI layer and the three engines of
+// libvqahip.so.  Not installed; the public interface is include/vqa_hip.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/vqa_hip.h"
+
+namespace vqa {
+
+// ---- errors ----------------------------------------------------------------
+void set_error(const char* fmt, ...);
+#define VQA_FAIL(code, ...)            \
+    do {                               \
+        ::vqa::set_error(__VA_ARGS__); \
+        return (code);                 \
+    } while (0)
+#define VQA_HIP(call)                                                                  \
+    do {                                                                               \
+        hipError_t _e = (call);                                                        \
+        if (_e != hipSuccess)                                                          \
+            VQA_FAIL(VQA_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), \
+                     __FILE__, __LINE__);                                              \
+    } while (0)
+
+// ---- which instance does what ----------------------------------------------
+// Either an explicit list (sample_idx / shift_param / shift_val, any of which
+// may be null) or the implicit full parameter-shift sweep: instance e is
+// sample sel[e / K] (or e / K), K = 2P+1, k = e % K: 0 = unshifted,
+// 2i+1 = +shift on parameter i, 2i+2 = -shift.
+struct EvalSpec {
+    const int32_t* sample_idx;
+    const int32_t* shift_param;
+    const double* shift_val;
+    const int32_t* sel;
+    int psr;
+    int P;
+    double shift;
+};
+
+__device__ __forceinline__ void decode_eval(const EvalSpec& sp, int64_t e, int& b, int& sparam,
+                                            double& sval) {
+    if (sp.psr) {
+        const int K = 2 * sp.P + 1;
+        const int64_t j = e / K;
+        const int k = (int)(e - j * K);
+        b = sp.sel ? sp.sel[j] : (int)j;
+        if (k == 0) {
+            sparam = -1;
+            sval = 0.0;
+        } else {
+            sparam = (k - 1) >> 1;
+            sval = (k & 1) ? sp.shift : -sp.shift;
+        }
+    } else {
+        b = sp.sample_idx ? sp.sample_idx[e] : (int)e;
+        sparam = sp.shift_param ? sp.shift_param[e] : -1;
+        sval = sp.shift_val ? sp.shift_val[e] : 0.0;
+    }
+}
+
+__device__ __forceinline__ double op_angle(const vqa_op& op, const double* theta,
+                                           const double* in_row, int sparam, double sval) {
+    double v = 0.0;
+    if (op.src == VQA_SRC_THETA) {
+        v = theta[op.idx];
+        if (op.idx == sparam) v += sval;
+    } else if (op.src == VQA_SRC_INPUT) {
+        v = in_row[op.idx];
+    }
+    return op.coef * v + op.offset;
+}
+
+// ---- observables, passed to kernels by value --------------------------------
+constexpr int kMaxObs = 16;
+constexpr int kMaxTerms = 96;
+struct ObsPack {
+    int n_obs;
+    int n_terms;
+    int off[kMaxObs + 1];
+    double coef[kMaxTerms];
+    uint64_t z[kMaxTerms];
+    uint64_t x[kMaxTerms];
+};
+
+// ---- handles ------------------------------------------------------------------
+struct DeviceCtx {  // per (circuit, device)
+    vqa_op* d_ops = nullptr;
+    void* reg_prog = nullptr;  // engine-2 compiled program (device copy)
+};
+
+}  // namespace vqa
+
+struct vqa_obs {
+    int n_qubits;
+    std::vector<double> coef;
+    std::vector<uint64_t> z, x;
+};
+
+namespace vqa {
+struct RegProgram;  // engine 2 (kern_reg.hip)
+}
+
+struct vqa_circuit {
+    int n_qubits, n_ops, n_theta, n_input;
+    int engine;  // resolved engine: 1 LDS, 2 register-blocked, 3 HBM
+    std::vector<vqa_op> ops;
+    std::shared_ptr<vqa::RegProgram> reg;  // host copy of the engine-2 program (may be null)
+    std::mutex mu;
+    std::map<int, vqa::DeviceCtx> dev;
+};
+
+namespace vqa {
+
+struct EvalCall {  // one batched evaluation, all pointers on the device
+    vqa_circuit* c;
+    int device;
+    hipStream_t stream;
+    const vqa_op* d_ops;
+    const double* d_theta;
+    const double* d_input;
+    EvalSpec spec;
+    int64_t E;
+    ObsPack obs;
+    int n_marg_bits;
+    double* d_out_expect;
+    double* d_out_marginal;
+};
+
+// engines: each returns VQA_OK or an error code with set_error() called
+int lds_engine_run(const EvalCall& call);
+int lds_engine_max_qubits();
+int hbm_engine_run(const EvalCall& call);
+int hbm_engine_statevector(const EvalCall& call, double* d_out_state);
+
+// per-device workspace owned by the library (grown on demand, never shrunk)
+int workspace_get(int device, size_t bytes, void** out);
+
+}  // namespace vqa
