@@ -151,8 +151,10 @@ int vqa_eval_batch(vqa_circuit* c, int device,
 
 /*
  * Same computation with every data pointer a DEVICE pointer on `device`, queued
- * on `stream` (a hipStream_t; NULL = the library's own stream for the device)
- * and not waited for.  Inputs may stay resident in HBM between calls.
+ * on `stream` (a hipStream_t; NULL = HIP's default stream) and not waited for.
+ * Inputs may stay resident in HBM between calls.  Instance lists cannot be
+ * checked on the host here: an instance that names a sample >= B or a
+ * parameter >= P gets NaN in all its outputs.
  */
 int vqa_eval_batch_dev(vqa_circuit* c, int device, void* stream,
                        const double* d_theta, const double* d_input_angles, int B,

@@ -194,17 +194,24 @@ __global__ __launch_bounds__(kT) void k_xpart(const double2* st, int n, uint64_t
 __global__ __launch_bounds__(kT) void k_finish(const double* partial, int nb, int nz, ZBatch zb,
                                                int use_coef, double xcoef, double* out,
                                                int64_t e_base, int stride, int col0, int spread,
-                                               int accumulate) {
+                                               int accumulate, EvalSpec spec) {
     __shared__ double red[4];
     const int ci = blockIdx.x;
     double total = 0.0;
+    bool valid;
+    {
+        int b_, sp_;
+        double sv_;
+        valid = decode_eval(spec, e_base + ci, b_, sp_, sv_);
+    }
+    const double nanv = __longlong_as_double(0x7ff8000000000000LL);
     for (int t = 0; t < nz; ++t) {
         double v = 0.0;
         for (int b = threadIdx.x; b < nb; b += kT) v += partial[((int64_t)ci * nb + b) * kZBatch + t];
         const double r = block_sum(v, red);
         if (threadIdx.x == 0) {
             if (spread) {  // one output column per t (marginal bins)
-                out[(e_base + ci) * stride + col0 + t] = r;
+                out[(e_base + ci) * stride + col0 + t] = valid ? r : nanv;
             } else {
                 total += (use_coef ? zb.coef[t] : xcoef) * r;
             }
@@ -212,7 +219,7 @@ __global__ __launch_bounds__(kT) void k_finish(const double* partial, int nb, in
     }
     if (!spread && threadIdx.x == 0) {
         double* o = &out[(e_base + ci) * stride + col0];
-        *o = accumulate ? *o + total : total;
+        *o = !valid ? nanv : accumulate ? *o + total : total;
     }
 }
 
@@ -306,7 +313,7 @@ int hbm_engine_run(const EvalCall& call) {
                                    partial);
                 hipLaunchKernelGGL(k_finish, dim3(h.C), dim3(kT), 0, call.stream, partial, nb,
                                    zb.nz, zb, 1, 0.0, call.d_out_expect, e0, n_obs, o, 0,
-                                   first ? 0 : 1);
+                                   first ? 0 : 1, call.spec);
                 first = false;
                 zb.nz = 0;
             };
@@ -324,7 +331,7 @@ int hbm_engine_run(const EvalCall& call) {
                                        call.obs.z[t], call.obs.x[t], partial);
                     hipLaunchKernelGGL(k_finish, dim3(h.C), dim3(kT), 0, call.stream, partial, nb,
                                        1, zb, 0, call.obs.coef[t], call.d_out_expect, e0, n_obs, o,
-                                       0, first ? 0 : 1);
+                                       0, first ? 0 : 1, call.spec);
                     first = false;
                 }
             }
@@ -332,7 +339,7 @@ int hbm_engine_run(const EvalCall& call) {
                 ZBatch z0;
                 z0.nz = 0; z0.marg_bits = 0; z0.m0 = 0;
                 hipLaunchKernelGGL(k_finish, dim3(h.C), dim3(kT), 0, call.stream, partial, nb, 0,
-                                   z0, 1, 0.0, call.d_out_expect, e0, n_obs, o, 0, 0);
+                                   z0, 1, 0.0, call.d_out_expect, e0, n_obs, o, 0, 0, call.spec);
             }
         }
         if (call.n_marg_bits > 0) {
@@ -345,7 +352,7 @@ int hbm_engine_run(const EvalCall& call) {
                 hipLaunchKernelGGL(k_zpart, dim3(nb, h.C), dim3(kT), 0, call.stream, st, n, zb,
                                    partial);
                 hipLaunchKernelGGL(k_finish, dim3(h.C), dim3(kT), 0, call.stream, partial, nb,
-                                   zb.nz, zb, 0, 0.0, call.d_out_marginal, e0, M, m0, 1, 0);
+                                   zb.nz, zb, 0, 0.0, call.d_out_marginal, e0, M, m0, 1, 0, call.spec);
             }
         }
         VQA_HIP(hipGetLastError());

@@ -63,6 +63,13 @@ __global__ __launch_bounds__(kThreads) void k_lds_eval(LdsArgs a) {
     for (int64_t e0 = (int64_t)blockIdx.x * S; e0 < a.E; e0 += (int64_t)gridDim.x * S) {
         const int64_t e = e0 + sidx;
         const bool live = e < a.E;
+        bool valid = true;
+        if (live) {
+            int b_, sp_;
+            double sv_;
+            valid = decode_eval(a.spec, e, b_, sp_, sv_);
+        }
+        const double nanv = __longlong_as_double(0x7ff8000000000000LL);
 
         for (int k = p; k < D; k += TPS) st[k] = make_double2(k == 0 ? 1.0 : 0.0, 0.0);
 
@@ -177,7 +184,7 @@ __global__ __launch_bounds__(kThreads) void k_lds_eval(LdsArgs a) {
                 acc += a.obs.coef[t] * part;
             }
             const double tot = seg_reduce(acc, red, tid, p, TPS);
-            if (p == 0 && live) a.out_expect[e * a.obs.n_obs + o] = tot;
+            if (p == 0 && live) a.out_expect[e * a.obs.n_obs + o] = valid ? tot : nanv;
         }
         if (a.n_marg_bits > 0) {
             const int M = 1 << a.n_marg_bits;
@@ -190,7 +197,7 @@ __global__ __launch_bounds__(kThreads) void k_lds_eval(LdsArgs a) {
                     }
                 }
                 const double tot = seg_reduce(part, red, tid, p, TPS);
-                if (p == 0 && live) a.out_marginal[e * M + m] = tot;
+                if (p == 0 && live) a.out_marginal[e * M + m] = valid ? tot : nanv;
             }
         }
         __syncthreads();

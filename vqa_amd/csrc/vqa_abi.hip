@@ -292,7 +292,7 @@ static int eval_dev_common(vqa_circuit* c, int device, void* stream, const doubl
     DeviceCtx* ctx;
     rc = circuit_device_ctx(c, device, &ctx);
     if (rc) return rc;
-    call.stream = stream ? (hipStream_t)stream : ds->stream;
+    call.stream = (hipStream_t)stream;
     call.d_ops = ctx->d_ops;
     call.d_theta = d_theta;
     call.d_input = d_input;
@@ -313,7 +313,7 @@ int vqa_eval_batch_dev(vqa_circuit* c, int device, void* stream, const double* d
         VQA_FAIL(VQA_EINVAL, "shift_param and shift_val must both be given or both be NULL");
     if (!d_sample_idx && c && c->n_input > 0 && E > B)
         VQA_FAIL(VQA_EINVAL, "sample_idx is NULL but E (%lld) > B (%d)", (long long)E, B);
-    EvalSpec spec = { d_sample_idx, d_shift_param, d_shift_val, nullptr, 0, 0, 0.0 };
+    EvalSpec spec = { d_sample_idx, d_shift_param, d_shift_val, nullptr, 0, 0, 0.0, c ? (c->n_input > 0 ? B : 0) : 0, c ? c->n_theta : 0 };
     return eval_dev_common(c, device, stream, d_theta, d_input_angles, B, spec, E, obs, n_obs,
                            n_marg_bits, d_out_expect, d_out_marginal);
 }
@@ -326,7 +326,7 @@ int vqa_psr_full_dev(vqa_circuit* c, int device, void* stream, const double* d_t
     if (n_sel < 0) VQA_FAIL(VQA_EINVAL, "n_sel must be >= 0");
     if (!d_sel && c->n_input > 0 && n_sel > B)
         VQA_FAIL(VQA_EINVAL, "sel is NULL but n_sel (%d) > B (%d)", n_sel, B);
-    EvalSpec spec = { nullptr, nullptr, nullptr, d_sel, 1, c->n_theta, shift };
+    EvalSpec spec = { nullptr, nullptr, nullptr, d_sel, 1, c->n_theta, shift, c->n_input > 0 ? B : 0, c->n_theta };
     const int64_t E = (int64_t)n_sel * (2 * (int64_t)c->n_theta + 1);
     return eval_dev_common(c, device, stream, d_theta, d_input_angles, B, spec, E, obs, n_obs,
                            n_marg_bits, d_out_expect, d_out_marginal);
@@ -438,7 +438,7 @@ int vqa_statevector(vqa_circuit* c, int device, const double* theta, const doubl
     call.d_ops = ctx->d_ops;
     call.d_theta = (double*)dth.p;
     call.d_input = (double*)din.p;
-    call.spec = EvalSpec{ nullptr, (int32_t*)dsp.p, (double*)dsv.p, nullptr, 0, 0, 0.0 };
+    call.spec = EvalSpec{ nullptr, (int32_t*)dsp.p, (double*)dsv.p, nullptr, 0, 0, 0.0, 0, c->n_theta };
     call.E = 1;
     memset(&call.obs, 0, sizeof(call.obs));
     call.n_marg_bits = 0;

@@ -43,9 +43,13 @@ struct EvalSpec {
     int psr;
     int P;
     double shift;
+    int B;        // rows of input_angles (sample indices are checked against it on the device)
+    int n_theta;  // parameters (shift_param is checked against it)
 };
 
-__device__ __forceinline__ void decode_eval(const EvalSpec& sp, int64_t e, int& b, int& sparam,
+// Returns false (and a harmless b = 0, no shift) when the instance names a
+// sample or parameter that does not exist; the caller then writes NaN for it.
+__device__ __forceinline__ bool decode_eval(const EvalSpec& sp, int64_t e, int& b, int& sparam,
                                             double& sval) {
     if (sp.psr) {
         const int K = 2 * sp.P + 1;
@@ -64,6 +68,13 @@ __device__ __forceinline__ void decode_eval(const EvalSpec& sp, int64_t e, int& 
         sparam = sp.shift_param ? sp.shift_param[e] : -1;
         sval = sp.shift_val ? sp.shift_val[e] : 0.0;
     }
+    const bool ok = (sp.B == 0 || (unsigned)b < (unsigned)sp.B) && sparam >= -1 && sparam < sp.n_theta;
+    if (!ok) {
+        b = 0;
+        sparam = -1;
+        sval = 0.0;
+    }
+    return ok;
 }
 
 __device__ __forceinline__ double op_angle(const vqa_op& op, const double* theta,

@@ -125,7 +125,9 @@ class LearningCircuit(GateList):
         torch = _torch()
         if isinstance(arr, torch.Tensor):
             t = arr.to(device=f"cuda:{self.device}")
-            return t.contiguous() if dtype is None else t.to(dtype).contiguous()
+            if dtype is not None:
+                t = t.to({np.float64: torch.float64, np.int32: torch.int32}[dtype])
+            return t.contiguous()
         a = np.ascontiguousarray(arr, dtype=dtype)
         return torch.from_numpy(a).to(f"cuda:{self.device}")
 
