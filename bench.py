@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: full parameter-shift gradient evaluation of the
+12-qubit hardware-efficient QNN (IBM feature map + depth-10 trainable block,
+636 gates, 396 circuit parameters) over a batch of 65536 samples per GPU.
+
+One "step" = one pass of the hot path over the batch: B * (2P+1) circuit
+evaluations on the GPU (vqa_psr_full_dev, inputs resident in HBM), the
+per-sample products and batch means that turn them into the regressor's MSE
+gradient (vqa/QNN/myQNNs_base.py:1378-1394), and for N > 1 one all-reduce of the
+P+1 gradient sums over RCCL.
+
+Usage: python bench.py --gpus N --steps K --warmup W
+(N > 1: launched by torch.distributed.run, one rank per GPU.)
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# peaks from the MI355X micro-architecture guide: LDS ds_read_b64/b128 with every
+# CU streaming ~150 TB/s aggregate; FP64 vector 78.6 TFLOP/s (half the 157.3 FP32)
+LDS_PEAK_GBS = 150_000.0
+FP64_PEAK_TFLOPS = 78.6
+
+WORKLOADS = {
+    # name: (n_qubits, depth, batch per GPU)
+    "hea12_d10_b65536": (12, 10, 65536),
+    "hea6_d5_b4096": (6, 5, 4096),
+}
+
+
+def alg_work(n, d):
+    """Algorithmic, unfused work per circuit evaluation of the IBM-HEA circuit:
+    every gate = one read + one write of the state (2*16*2^n bytes) plus one
+    final read for the observable; flops: dense 1q gate 14*2^n, diagonal 1q
+    6*2^n, CNOT/CZ 0, Z-string expectation 3*2^n."""
+    G = 13 * n + 4 * n * d
+    dense = 2 * n + 2 * n * (d + 1)
+    diag = 4 * n + n * (d + 1)
+    D = 1 << n
+    return G, (G * 32 + 16) * D, (dense * 14 + diag * 6 + 3) * D
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="hea12_d10_b65536", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=None, help="override the per-GPU batch (not a valid headline number)")
+    ap.add_argument("--engine", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"WORLD_SIZE={world} does not match --gpus {args.gpus}", file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py needs a GPU: the HIP engine has no CPU fallback", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+
+    from vqa_amd import LearningCircuit, Observable, _lib, create_ibm_HEA_ansatz
+
+    n, d, B = WORKLOADS[args.workload]
+    if args.batch:
+        B = args.batch
+    if args.engine:
+        _lib.check(_lib.lib().vqa_set_engine(args.engine))
+    circ = create_ibm_HEA_ansatz(n, d, seed=0, circuit_cls=lambda nq: LearningCircuit(nq, device=local_rank))
+    P = circ.n_theta
+    K = 2 * P + 1
+    z0 = Observable(n)
+    z0.add_operator(1.0, "Z 0")
+
+    # synthetic data of the benchmark's shape: x ~ U(0, pi)^n, y = a smooth target
+    rng = np.random.default_rng(2 + rank)
+    x = rng.uniform(0.0, np.pi, (B, n))
+    y = np.sin(x.sum(axis=1))
+    theta = np.random.default_rng(0).uniform(0.0, 2 * np.pi, P)
+    w = 1.0
+    # vectorised restatement of the ansatz' input functions (one row per sample)
+    xi = x
+    zz = (np.pi - x) * (np.pi - x[:, :1])
+    one = np.empty((B, 2 * n))
+    one[:, 0::2] = xi
+    one[:, 1::2] = zz
+    ia = np.concatenate([one, one], axis=1)
+    chk = circ.input_angles(x[:4])
+    assert np.allclose(chk, ia[:4]), "vectorised input angles disagree with the circuit's input functions"
+
+    dev = torch.device(f"cuda:{local_rank}")
+    d_in = torch.from_numpy(np.ascontiguousarray(ia)).to(dev)
+    d_theta = torch.from_numpy(theta).to(dev)
+    d_y = torch.from_numpy(y).to(dev)
+    d_out = torch.empty((B, K, 1), dtype=torch.float64, device=dev)
+    grad_sums = torch.zeros(P + 1, dtype=torch.float64, device=dev)
+
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+
+    def step(i=None):
+        if i is not None:
+            ev0[i].record()
+        circ.psr_full(d_theta, d_in, n_sel=B, obs_list=[z0], out_expect=d_out)
+        if i is not None:
+            ev1[i].record()
+        e = d_out[:, :, 0]
+        e0 = e[:, 0]
+        resid = (w * e0 - d_y) * w
+        grad_sums[:P] = (resid[:, None] * (e[:, 1::2] - e[:, 2::2])).sum(dim=0)
+        grad_sums[P] = (2.0 * (-d_y * e0 + w * e0 * e0)).sum()
+        if world > 1:
+            dist.all_reduce(grad_sums)
+        return grad_sums / (B * world)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        g = step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+    assert bool(torch.isfinite(g).all()), "gradient is not finite"
+
+    if rank == 0:
+        evals = B * K
+        G, bytes_alg, flops_alg = alg_work(n, d)
+        evals_per_s_kernel = evals / (kern_ms * 1e-3)
+        grads_per_s = B * world * args.steps / dt
+        res = {
+            "metric": "parameter-shift gradients/sec",
+            "value": grads_per_s,
+            "unit": "gradients/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "circuit_evals_per_sec": evals * world * args.steps / dt,
+            "config": {
+                "workload": f"{n}-qubit IBM-HEA QNN regressor, depth {d}, {G} gates, P={P}, "
+                            f"batch {B} samples per GPU, full parameter shift ({K} evaluations per sample)",
+                "n_qubits": n, "depth": d, "batch_per_gpu": B, "n_params": P,
+                "evals_per_step_per_gpu": evals, "engine": args.engine or "auto",
+                "prefix_reuse": False,
+            },
+            "roofline": {
+                "bound": "lds",
+                "achieved": bytes_alg * evals_per_s_kernel / 1e9,
+                "peak": LDS_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": bytes_alg * evals_per_s_kernel / 1e9 / LDS_PEAK_GBS,
+                "traffic": None,
+                "kernel_ms_per_launch": kern_ms,
+                "alg_bytes_per_eval": bytes_alg,
+                "fp64": {
+                    "achieved": flops_alg * evals_per_s_kernel / 1e12,
+                    "peak": FP64_PEAK_TFLOPS,
+                    "unit": "TFLOP/s",
+                    "frac": flops_alg * evals_per_s_kernel / 1e12 / FP64_PEAK_TFLOPS,
+                    "alg_flops_per_eval": flops_alg,
+                },
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(circ, theta, ia, P, args.cpu_seconds)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(circ, theta, ia, P, seconds):
+    """The CPU oracle (a port of the qulacs-convention arithmetic; the reference's
+    own CPU path, qulacs, is not installed) timed on this host's cores on a
+    bounded sample of the same workload."""
+    from oracle import cpu_oracle
+
+    K = 2 * P + 1
+    threads = int(os.environ.get("OMP_NUM_THREADS", 0)) or min(os.cpu_count() or 1, 16)
+    z0 = ([1.0], [1])
+    si, sp, sv = cpu_oracle.psr_lists(1, P)
+    probe = 4 * threads
+    t0 = time.perf_counter()
+    cpu_oracle.eval_batch(circ, theta, ia, si[:probe], sp[:probe], sv[:probe], obs_list=[z0], n_threads=threads)
+    per = (time.perf_counter() - t0) / probe
+    n_eval = int(max(probe, min(seconds / per, 64 * K)))
+    n_s = (n_eval + K - 1) // K
+    si, sp, sv = cpu_oracle.psr_lists(n_s, P)
+    si, sp, sv = si[:n_eval], sp[:n_eval], sv[:n_eval]
+    t0 = time.perf_counter()
+    cpu_oracle.eval_batch(circ, theta, ia, si, sp, sv, obs_list=[z0], n_threads=threads)
+    dt = time.perf_counter() - t0
+    return {
+        "value": n_eval / dt / K,
+        "unit": "gradients/s",
+        "circuit_evals_per_sec": n_eval / dt,
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{n_eval} circuit evaluations (first {n_s} samples of the same batch, same shifts), "
+                  f"{threads} OpenMP threads, {dt:.1f} s",
+    }
+
+
+if __name__ == "__main__":
+    main()

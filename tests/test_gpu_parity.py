@@ -42,6 +42,25 @@ def compare(c, theta, x, obs_list, marg, si=None, sp=None, sv=None, device_path=
         assert np.abs(got_m.sum(axis=1) - 1).max() < TOL
 
 
+@pytest.mark.parametrize("n", [4, 5, 6, 7, 8, 9, 10, 11, 12])
+@pytest.mark.parametrize("xy", [False, True])
+def test_random_circuits_register_engine(n, xy):
+    """Engine 2 (register-blocked); with X/Y Pauli terms the call is served by
+    the gate-by-gate engine behind the same handle."""
+    set_engine("reg")
+    c = random_circuit(LearningCircuit, n, 70, seed=300 + n)
+    rng = np.random.default_rng(50 + n)
+    theta = rng.uniform(-3, 3, c.n_theta)
+    x = rng.uniform(-1, 1, (9, 3))
+    E = 37
+    si = rng.integers(0, 9, E).astype(np.int32)
+    sp = rng.integers(-1, c.n_theta, E).astype(np.int32)
+    sv = rng.choice([0.5 * np.pi, -0.5 * np.pi, 0.3], E)
+    obs = random_observables(n, seed=n, xy=xy)
+    compare(c, theta, x, obs, 2, si, sp, sv)
+    compare(c, theta, x, obs, 2, si, sp, sv, device_path=True)
+
+
 @pytest.mark.parametrize("engine", ["lds", "hbm"])
 @pytest.mark.parametrize("n", [1, 2, 3, 5, 6, 8, 9, 10, 12])
 def test_random_circuits_all_gate_kinds(engine, n):
@@ -59,7 +78,9 @@ def test_random_circuits_all_gate_kinds(engine, n):
     compare(c, theta, x, obs, min(n, 2), si, sp, sv, device_path=True)
 
 
-@pytest.mark.parametrize("engine,n,d", [("lds", 4, 2), ("lds", 6, 5), ("lds", 12, 2), ("lds", 13, 1),
+@pytest.mark.parametrize("engine,n,d", [("reg", 4, 2), ("reg", 6, 5), ("reg", 9, 2), ("reg", 11, 2), ("reg", 12, 2),
+                                        ("reg", 12, 10), ("reg", 13, 1),
+                                        ("lds", 4, 2), ("lds", 6, 5), ("lds", 12, 2), ("lds", 13, 1),
                                         ("hbm", 6, 2), ("hbm", 14, 1), ("hbm", 16, 1)])
 def test_ibm_hea_full_parameter_shift(engine, n, d):
     set_engine(engine)
@@ -86,8 +107,8 @@ def test_ibm_hea_full_parameter_shift(engine, n, d):
     assert np.abs(got_m2.cpu().numpy().reshape(-1, 4) - want_m).max() < TOL
 
 
-@pytest.mark.parametrize("engine", ["lds", "hbm"])
-@pytest.mark.parametrize("builder,n,d", [(create_jerbi_ansatz, 5, 2), (create_jerbi_ansatz, 9, 1),
+@pytest.mark.parametrize("engine", ["reg", "lds", "hbm"])
+@pytest.mark.parametrize("builder,n,d", [(create_jerbi_ansatz, 5, 2), (create_jerbi_ansatz, 9, 1), (create_jerbi_ansatz, 12, 1),
                                          (create_ry_rz_cz_ansatz, 4, 3), (create_ry_cz_ansatz, 10, 3)])
 def test_other_ansaetze(engine, builder, n, d):
     set_engine(engine)
@@ -95,7 +116,7 @@ def test_other_ansaetze(engine, builder, n, d):
     rng = np.random.default_rng(7)
     theta = rng.uniform(0, 2 * np.pi, c.n_theta)
     x = rng.uniform(0, np.pi, (6, n))
-    obs = random_observables(n, seed=3, xy=(builder is create_ry_cz_ansatz))
+    obs = random_observables(n, seed=3, xy=(builder is create_ry_cz_ansatz and engine != "reg"))
     compare(c, theta, x, obs, 2)
 
 

@@ -1,0 +1,407 @@
+// Host-side circuit compiler of engine 2: gate list -> normal form of
+// alternating U-/D-stages -> schedule of register / lane / LDS-transposition
+// operations (format: reg_program.h).
+//
+// The gate lists it is tuned for are the reference's ansaetze
+// (vqa/QNN/QML_utils.py:33-164): H layers, ZZ feature maps written as
+// CNOT-RZ-CNOT sandwiches, RX/RY/RZ layers and CZ rings; any list of the
+// supported gate kinds compiles.
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <random>
+#include <string>
+#include <utility>
+
+#include "reg_program.h"
+
+namespace vqa {
+
+namespace {
+
+struct Stage {
+    bool isU = true;
+    // U: qubit -> elementary gates in time order
+    std::map<int, std::vector<ElemGate>> g;
+    // D: single-qubit RZ terms, ZZ terms, CZ pairs, Z gates
+    std::map<int, std::vector<ElemGate>> rz;
+    std::map<std::pair<int, int>, std::vector<ElemGate>> zz;
+    std::vector<std::pair<int, int>> cz;
+    std::vector<int> z;
+
+    bool touches(int q) const {
+        if (rz.count(q)) return true;
+        for (int zq : z) if (zq == q) return true;
+        for (auto& kv : zz) if (kv.first.first == q || kv.first.second == q) return true;
+        for (auto& p : cz) if (p.first == q || p.second == q) return true;
+        return false;
+    }
+};
+
+ElemGate elem_of(const vqa_op& op) {
+    ElemGate e;
+    e.kind = op.kind;
+    e.src = (op.kind >= VQA_GATE_RX && op.kind <= VQA_GATE_RZ) ? op.src : VQA_SRC_CONST;
+    e.idx = op.idx;
+    e.pad = 0;
+    e.coef = op.coef;
+    e.offset = op.offset;
+    return e;
+}
+
+ElemGate fixed_gate(int kind) {
+    ElemGate e;
+    memset(&e, 0, sizeof(e));
+    e.kind = kind;
+    e.src = VQA_SRC_CONST;
+    return e;
+}
+
+void add_1q(std::vector<Stage>& st, int q, const ElemGate& e) {
+    const bool diag = e.kind == VQA_GATE_RZ || e.kind == VQA_GATE_Z;
+    if (!st.empty() && st.back().isU) {
+        st.back().g[q].push_back(e);
+        return;
+    }
+    if (!st.empty()) {  // last stage is a D-stage
+        Stage& d = st.back();
+        if (diag) {
+            if (e.kind == VQA_GATE_RZ) d.rz[q].push_back(e);
+            else d.z.push_back(q);
+            return;
+        }
+        if (!d.touches(q) && st.size() >= 2) {  // commutes with the D-stage: join the U-stage before it
+            st[st.size() - 2].g[q].push_back(e);
+            return;
+        }
+    }
+    Stage u;
+    u.isU = true;
+    u.g[q].push_back(e);
+    st.push_back(u);
+}
+
+Stage& last_d(std::vector<Stage>& st) {
+    if (st.empty() || st.back().isU) {
+        Stage d;
+        d.isU = false;
+        st.push_back(d);
+    }
+    return st.back();
+}
+
+std::vector<Stage> normal_form(const std::vector<vqa_op>& ops) {
+    std::vector<Stage> st;
+    const size_t N = ops.size();
+    for (size_t i = 0; i < N; ++i) {
+        const vqa_op& o = ops[i];
+        if (o.kind == VQA_GATE_CNOT) {
+            // CNOT(c,t) RZ_t(a) CNOT(c,t) = exp(i a/2 Z_c Z_t)
+            if (i + 2 < N && ops[i + 1].kind == VQA_GATE_RZ && ops[i + 1].q0 == o.q0 &&
+                ops[i + 2].kind == VQA_GATE_CNOT && ops[i + 2].q0 == o.q0 && ops[i + 2].q1 == o.q1) {
+                Stage& d = last_d(st);
+                d.zz[std::minmax(o.q0, o.q1)].push_back(elem_of(ops[i + 1]));
+                i += 2;
+                continue;
+            }
+            // lone CNOT = H_t CZ(c,t) H_t
+            add_1q(st, o.q0, fixed_gate(VQA_GATE_H));
+            last_d(st).cz.push_back({o.q0, o.q1});
+            add_1q(st, o.q0, fixed_gate(VQA_GATE_H));
+        } else if (o.kind == VQA_GATE_CZ) {
+            last_d(st).cz.push_back({o.q0, o.q1});
+        } else {
+            add_1q(st, o.q0, elem_of(o));
+        }
+    }
+    // a leading D-stage acts on |0...0> (global phase); a trailing one does not
+    // change Z-basis probabilities, which is all this engine measures
+    if (!st.empty() && !st.front().isU) st.erase(st.begin());
+    if (!st.empty() && !st.back().isU) st.pop_back();
+    return st;
+}
+
+// ---- GF(2) helpers -------------------------------------------------------------
+int gf2_rank(std::vector<uint32_t> rows) {
+    int rank = 0;
+    for (int bit = 0; bit < 32; ++bit) {
+        int piv = -1;
+        for (size_t i = rank; i < rows.size(); ++i)
+            if (rows[i] >> bit & 1) { piv = (int)i; break; }
+        if (piv < 0) continue;
+        std::swap(rows[rank], rows[piv]);
+        for (size_t i = 0; i < rows.size(); ++i)
+            if ((int)i != rank && (rows[i] >> bit & 1)) rows[i] ^= rows[rank];
+        ++rank;
+    }
+    return rank;
+}
+
+inline int par(uint32_t x) { return __builtin_popcount(x) & 1; }
+
+// Find an invertible XOR-linear slot function (masks f[k]: slot bit k =
+// parity(index & f[k])) whose low bits are conflict-free for the 16-byte LDS
+// writes in the old layout (8 consecutive lanes -> 8 distinct slots mod 8) and
+// for the 16-byte reads in the new layout (the 16-lane read groups of the LDS
+// -> 16 distinct slots mod 16).  sigma[p'] = old position read by new position p'.
+std::vector<uint32_t> find_swizzle(int n, const int* sigma) {
+    const int R = kRegBits;
+    const uint32_t w[3] = { 1u << (R + 0), 1u << (R + 1), 1u << (R + 2) };
+    const uint32_t v[4] = { 1u << sigma[R + 0], 1u << sigma[R + 1],
+                            (1u << sigma[R + 2]) ^ (1u << sigma[R + 3]),
+                            (1u << sigma[R + 2]) ^ (1u << sigma[R + 4]) };
+    uint32_t involved = 0;
+    for (auto x : w) involved |= x;
+    for (auto x : v) involved |= x;
+    std::vector<int> bits;
+    for (int p = 0; p < n; ++p) if (involved >> p & 1) bits.push_back(p);
+    std::mt19937 rng(12345);
+    std::vector<uint32_t> f(4, 0);
+    bool ok = false;
+    for (int attempt = 0; attempt < 200000 && !ok; ++attempt) {
+        for (int k = 0; k < 4; ++k) {
+            uint32_t m = 0;
+            const int cnt = 1 + (int)(rng() % 3);
+            for (int c = 0; c < cnt; ++c) m |= 1u << bits[rng() % bits.size()];
+            f[k] = m;
+        }
+        std::vector<uint32_t> mw(3), mr(4);
+        for (int i = 0; i < 3; ++i) { mw[i] = 0; for (int k = 0; k < 3; ++k) mw[i] |= (uint32_t)par(w[i] & f[k]) << k; }
+        for (int i = 0; i < 4; ++i) { mr[i] = 0; for (int k = 0; k < 4; ++k) mr[i] |= (uint32_t)par(v[i] & f[k]) << k; }
+        if (gf2_rank(mw) == 3 && gf2_rank(mr) == 4 && gf2_rank(f) == 4) ok = true;
+    }
+    if (!ok) {  // correct but possibly conflicting: identity slots
+        std::vector<uint32_t> id(n);
+        for (int p = 0; p < n; ++p) id[p] = 1u << p;
+        return id;
+    }
+    for (int p = 0; p < n && (int)f.size() < n; ++p) {
+        std::vector<uint32_t> t = f;
+        t.push_back(1u << p);
+        if (gf2_rank(t) == (int)t.size()) f = t;
+    }
+    return f;
+}
+
+template <class T>
+int64_t place(std::vector<char>& blob, const std::vector<T>& v) {
+    while (blob.size() % 16) blob.push_back(0);
+    const int64_t off = (int64_t)blob.size();
+    const char* p = (const char*)v.data();
+    blob.insert(blob.end(), p, p + v.size() * sizeof(T));
+    return off;
+}
+
+}  // namespace
+
+bool reg_compile(int n, const std::vector<vqa_op>& gate_list, RegProgram* out, std::string* why) {
+    const int R = kRegBits;
+    if (n < R) { *why = "fewer qubits than register bits"; return false; }
+    const int T = n - R;
+    if (T > kMaxThreadBits || T > 9) { *why = "too many qubits for one workgroup"; return false; }
+    const int L = std::min(T, 6), W = T - L;
+    RegProgram& P = *out;
+    P = RegProgram();
+    RegHeader& H = P.hdr;
+    memset(&H, 0, sizeof(H));
+    H.n = n; H.T = T; H.L = L; H.W = W;
+    H.block = std::max(64, 1 << T);
+    H.S = H.block >> T;
+
+    std::vector<Stage> st = normal_form(gate_list);
+    // strict alternation U D U ... U is guaranteed by construction
+    std::vector<int> ustages, dstages;
+    for (size_t i = 0; i < st.size(); ++i) (st[i].isU ? ustages : dstages).push_back((int)i);
+    const int NU = (int)ustages.size(), ND = (int)dstages.size();
+    if (NU > 0 && ND != NU - 1) { *why = "internal: stages do not alternate"; return false; }
+
+    // ---- per-evaluation tables ----
+    // ph1: D-stage d, qubit q -> index d*n + q
+    std::vector<std::map<int, int>> uidx(NU);  // U-stage -> qubit -> U-entry index
+    for (int u = 0; u < NU; ++u) {
+        for (auto& kv : st[ustages[u]].g) {
+            UEntry e;
+            e.begin = (int)P.elems.size();
+            e.count = (int)kv.second.size();
+            P.elems.insert(P.elems.end(), kv.second.begin(), kv.second.end());
+            e.d_before = u > 0 ? (u - 1) * n + kv.first : -1;
+            e.d_after = u < NU - 1 ? u * n + kv.first : -1;
+            e.parity = u & 1;
+            e.pad = 0;
+            uidx[u][kv.first] = (int)P.uent.size();
+            P.uent.push_back(e);
+            ++P.n_dense_gates;
+        }
+    }
+    std::vector<std::map<std::pair<int, int>, int>> d2idx(ND);
+    for (int d = 0; d < ND; ++d) {
+        const Stage& s = st[dstages[d]];
+        for (int q = 0; q < n; ++q) {
+            D1Entry e;
+            e.begin = (int)P.terms.size();
+            auto it = s.rz.find(q);
+            if (it != s.rz.end()) P.terms.insert(P.terms.end(), it->second.begin(), it->second.end());
+            e.count = (int)P.terms.size() - e.begin;
+            P.d1.push_back(e);
+        }
+        for (auto& kv : s.zz) {
+            D2Entry e;
+            e.begin = (int)P.terms.size();
+            P.terms.insert(P.terms.end(), kv.second.begin(), kv.second.end());
+            e.count = (int)P.terms.size() - e.begin;
+            d2idx[d][kv.first] = (int)P.d2.size();
+            P.d2.push_back(e);
+        }
+    }
+
+    // ---- schedule ----
+    int q_at[kMaxPos], pos_of[kMaxPos];
+    for (int p = 0; p < kMaxPos; ++p) { q_at[p] = p < n ? p : -1; pos_of[p] = p; }
+    auto emit = [&](int kind, int a, int b) { P.ops.push_back(RegOp{ kind, a, b, 0 }); };
+    auto emit_direct = [&](int q, int ue) {
+        const int p = pos_of[q];
+        if (p < R) emit(ROP_UREG, p, ue);
+        else emit(ROP_ULANE, p - R, ue);
+    };
+    auto cheap = [&](int p) { return p < R || p == R + 0 || p == R + 1 || p == R + 3; };
+    const int cheap_slots[7] = { 0, 1, 2, 3, R + 0, R + 1, R + 3 };
+
+    for (int u = 0; u < NU; ++u) {
+        std::vector<std::pair<int, int>> byq;  // (position, qubit)
+        for (auto& kv : uidx[u]) byq.push_back({ pos_of[kv.first], kv.first });
+        std::sort(byq.begin(), byq.end());
+        if (W == 0) {
+            for (auto& pq : byq) emit_direct(pq.second, uidx[u][pq.second]);
+        } else {
+            std::vector<int> remaining;
+            for (auto& pq : byq) {
+                if (cheap(pq.first)) emit_direct(pq.second, uidx[u][pq.second]);
+                else remaining.push_back(pq.second);
+            }
+            while (!remaining.empty()) {
+                bool any_wave = false;
+                for (int q : remaining) any_wave |= pos_of[q] >= R + L;
+                if (!any_wave && remaining.size() <= 1) {
+                    for (int q : remaining) emit_direct(q, uidx[u][q]);
+                    break;
+                }
+                const int nb = (int)std::min<size_t>(7, remaining.size());
+                int old_pos_of[kMaxPos];
+                memcpy(old_pos_of, pos_of, sizeof(pos_of));
+                for (int i = 0; i < nb; ++i) {
+                    const int qa = remaining[i], pa = pos_of[qa], pb = cheap_slots[i], qb = q_at[pb];
+                    q_at[pa] = qb; pos_of[qb] = pa;
+                    q_at[pb] = qa; pos_of[qa] = pb;
+                }
+                int sigma[kMaxPos];
+                for (int p = 0; p < n; ++p) sigma[p] = old_pos_of[q_at[p]];
+                std::vector<uint32_t> f = find_swizzle(n, sigma);
+                XDesc xd;
+                memset(&xd, 0, sizeof(xd));
+                for (int p = 0; p < n; ++p) {
+                    int slot = 0;
+                    for (int k = 0; k < n; ++k) slot |= (int)((f[k] >> p) & 1) << k;
+                    xd.wconst[p] = slot;
+                }
+                for (int p = 0; p < n; ++p) xd.rconst[p] = xd.wconst[sigma[p]];
+                emit(ROP_XPOSE, (int)P.xdesc.size(), 0);
+                P.xdesc.push_back(xd);
+                ++P.n_xpose;
+                for (int i = 0; i < nb; ++i) emit_direct(remaining[i], uidx[u][remaining[i]]);
+                remaining.erase(remaining.begin(), remaining.begin() + nb);
+            }
+        }
+        if (u < NU - 1) {
+            const Stage& s = st[dstages[u]];
+            DDesc dd;
+            memset(&dd, 0, sizeof(dd));
+            dd.ph1_base = u * n;
+            for (int p = 0; p < kMaxPos; ++p) dd.qubit_at_pos[p] = (int8_t)(p < n ? q_at[p] : -1);
+            std::vector<PairRef> tt, rt, rr;
+            for (auto& kv : s.zz) {
+                int pa = pos_of[kv.first.first], pb = pos_of[kv.first.second];
+                if (pa > pb) std::swap(pa, pb);
+                const int id = d2idx[u][kv.first];
+                if (pa >= R) tt.push_back(PairRef{ pa - R, pb - R, id, 0 });
+                else if (pb >= R) rt.push_back(PairRef{ pa, pb - R, id, 0 });
+                else rr.push_back(PairRef{ pa, pb, id, 0 });
+            }
+            dd.tt_begin = (int)P.pairs.size(); dd.tt_count = (int)tt.size();
+            P.pairs.insert(P.pairs.end(), tt.begin(), tt.end());
+            dd.rt_begin = (int)P.pairs.size(); dd.rt_count = (int)rt.size();
+            P.pairs.insert(P.pairs.end(), rt.begin(), rt.end());
+            dd.rr_begin = (int)P.pairs.size(); dd.rr_count = (int)rr.size();
+            P.pairs.insert(P.pairs.end(), rr.begin(), rr.end());
+            dd.has_sign = (!s.cz.empty() || !s.z.empty()) ? 1 : 0;
+            if (dd.has_sign) {
+                for (int t = 0; t < (1 << T); ++t) {
+                    int base = 0, cr[kRegBits] = { 0, 0, 0, 0 };
+                    for (auto& p : s.cz) {
+                        int pa = pos_of[p.first], pb = pos_of[p.second];
+                        if (pa > pb) std::swap(pa, pb);
+                        if (pa >= R) base ^= (t >> (pa - R)) & (t >> (pb - R)) & 1;
+                        else if (pb >= R) cr[pa] ^= (t >> (pb - R)) & 1;
+                    }
+                    for (int q : s.z) {
+                        const int p = pos_of[q];
+                        if (p >= R) base ^= (t >> (p - R)) & 1;
+                    }
+                    if (base) dd.tt_par[t >> 5] |= 1u << (t & 31);
+                    for (int j = 0; j < R; ++j) if (cr[j]) dd.cross[j][t >> 5] |= 1u << (t & 31);
+                }
+                for (int r = 0; r < kRegAmps; ++r) {
+                    int b = 0;
+                    for (auto& p : s.cz) {
+                        const int pa = pos_of[p.first], pb = pos_of[p.second];
+                        if (pa < R && pb < R) b ^= (r >> pa) & (r >> pb) & 1;
+                    }
+                    for (int q : s.z) {
+                        const int p = pos_of[q];
+                        if (p < R) b ^= (r >> p) & 1;
+                    }
+                    if (b) dd.rr_par |= 1u << r;
+                }
+            }
+            emit(ROP_DIAG, (int)P.ddesc.size(), 0);
+            P.ddesc.push_back(dd);
+            ++P.n_diag;
+        }
+    }
+    emit(ROP_END, 0, 0);
+    for (int p = 0; p < kMaxPos; ++p) H.final_qubit_at_pos[p] = (int8_t)(p < n ? q_at[p] : -1);
+
+    H.n_uent = (int)P.uent.size();
+    H.n_d1 = (int)P.d1.size();
+    H.n_d2 = (int)P.d2.size();
+    H.n_elems = (int)P.elems.size();
+    H.n_terms = (int)P.terms.size();
+    H.n_ops = (int)P.ops.size();
+    H.n_ddesc = (int)P.ddesc.size();
+    H.n_xdesc = (int)P.xdesc.size();
+    H.n_pairs = (int)P.pairs.size();
+    H.has_xpose = P.n_xpose > 0;
+
+    const size_t tab = (size_t)H.S * ((size_t)H.n_uent + H.n_d1 + H.n_d2) * 16;
+    const size_t xbuf = H.has_xpose ? ((size_t)16 << n) : 0;
+    P.lds_bytes = tab + xbuf + 64 * sizeof(double);
+    if (P.lds_bytes > 160 * 1024) { *why = "per-evaluation tables do not fit LDS"; return false; }
+
+    // ---- device blob ----
+    P.blob.assign(sizeof(RegHeader), 0);
+    H.off_elems = place(P.blob, P.elems);
+    H.off_uent = place(P.blob, P.uent);
+    H.off_d1 = place(P.blob, P.d1);
+    H.off_d2 = place(P.blob, P.d2);
+    H.off_terms = place(P.blob, P.terms);
+    H.off_ops = place(P.blob, P.ops);
+    H.off_ddesc = place(P.blob, P.ddesc);
+    H.off_xdesc = place(P.blob, P.xdesc);
+    H.off_pairs = place(P.blob, P.pairs);
+    while (P.blob.size() % 16) P.blob.push_back(0);
+    H.total_bytes = (int64_t)P.blob.size();
+    memcpy(P.blob.data(), &H, sizeof(H));
+    return true;
+}
+
+}  // namespace vqa

@@ -1,0 +1,135 @@
+// Program format of engine 2 (register-blocked fused engine), shared by the
+// host-side circuit compiler (reg_compile.cpp) and the kernel (kern_reg.hip).
+//
+// A circuit is brought into a normal form of alternating stages:
+//   U-stage: at most one 2x2 unitary per qubit (the product of the elementary
+//            1-qubit gates the submitted list applies to that qubit there);
+//   D-stage: a diagonal operator: single-qubit Z-phases, two-qubit ZZ-phases
+//            (from CNOT-RZ-CNOT sandwiches), CZ and Z signs.
+// Per evaluation every 2x2 is re-expressed on the device as
+//   e^{i d} RZ(alpha) RY(beta) RZ(gamma),
+// so the dense part applied to the amplitudes is a REAL rotation (4 flops per
+// amplitude instead of 8) and the phases e^{i alpha/2}, e^{i gamma/2} are merged
+// into the neighbouring D-stages.  The global phase is dropped.
+//
+// Amplitude index bits are "positions": 0..R-1 live in registers (2^R
+// amplitudes per thread), R..R+L-1 are lane bits, the rest are wave bits.  A
+// layout maps positions to qubits; transpositions through LDS change it.
+#pragma once
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/vqa_hip.h"
+
+namespace vqa {
+
+constexpr int kRegBits = 4;       // R: register-resident index bits
+constexpr int kRegAmps = 1 << kRegBits;
+constexpr int kMaxPos = 16;       // positions a layout can describe
+constexpr int kMaxThreadBits = 10;
+constexpr int kSignWords = (1 << kMaxThreadBits) / 32;
+
+enum RegOpKind : int32_t {
+    ROP_END = 0,
+    ROP_UREG = 1,    // a = register bit j,  b = U-entry index
+    ROP_ULANE = 2,   // a = lane bit l,      b = U-entry index
+    ROP_DIAG = 3,    // a = D-descriptor index
+    ROP_XPOSE = 4,   // a = transposition descriptor index
+};
+
+struct RegOp {
+    int32_t kind, a, b, c;
+};
+
+// an elementary 1-qubit gate inside a U-entry, or an angle term of a D-entry
+struct ElemGate {
+    int32_t kind;  // VQA_GATE_*
+    int32_t src;   // VQA_SRC_*
+    int32_t idx;
+    int32_t pad;
+    double coef, offset;
+};
+
+// one (U-stage, qubit): product of elems[begin, begin+count) in time order
+struct UEntry {
+    int32_t begin, count;
+    int32_t d_before;  // ph1 index that absorbs e^{i gamma/2} (-1: dropped)
+    int32_t d_after;   // ph1 index that absorbs e^{i alpha/2} (-1: dropped)
+    int32_t parity;    // U-stage index & 1 (the two prep phases)
+    int32_t pad;
+};
+
+// one single-qubit phase of a D-stage: exp(+i/2 * sum of angle terms) on |0>, conj on |1>
+struct D1Entry {
+    int32_t begin, count;  // into terms[]
+};
+// one ZZ phase of a D-stage: exp(+i/2 * sum) when the two bits agree, conj otherwise
+struct D2Entry {
+    int32_t begin, count;
+};
+
+struct PairRef {
+    int32_t a, b;   // positions (meaning depends on the list it is in)
+    int32_t ph2;    // index into the ph2 table
+    int32_t pad;
+};
+
+// a D-stage as applied in the layout current at that point of the program
+struct DDesc {
+    int32_t ph1_base;                 // ph1 index of qubit 0 of this stage (n consecutive entries)
+    int32_t tt_begin, tt_count;       // pairs with both qubits on thread bits: a, b = thread bit numbers
+    int32_t rt_begin, rt_count;       // a = register bit, b = thread bit number
+    int32_t rr_begin, rr_count;       // a, b = register bits
+    int32_t has_sign;                 // any CZ / Z in this stage
+    int8_t qubit_at_pos[kMaxPos];
+    uint32_t tt_par[kSignWords];      // bit t: sign parity from thread-only CZ/Z terms
+    uint32_t cross[kRegBits][kSignWords];  // bit t: parity flip when register bit j is set
+    uint32_t rr_par;                  // bit r: parity from register-only CZ/Z terms
+    int32_t pad;
+};
+
+// LDS transposition: slot(index) is XOR-linear; wconst[p] = slot of old-layout
+// position bit p, rconst[p] = slot of the old position that new position p reads.
+struct XDesc {
+    int32_t wconst[kMaxPos];
+    int32_t rconst[kMaxPos];
+};
+
+struct RegHeader {
+    int32_t n, T, L, W;          // qubits, thread bits, lane bits, wave bits
+    int32_t block;               // threads per workgroup
+    int32_t S;                   // states per workgroup
+    int32_t n_uent, n_d1, n_d2;  // per-evaluation table sizes (entries of 16 bytes)
+    int32_t n_elems, n_terms, n_ops, n_ddesc, n_xdesc, n_pairs;
+    int32_t has_xpose;
+    int8_t final_qubit_at_pos[kMaxPos];
+    // byte offsets of the arrays inside the device blob
+    int64_t off_elems, off_uent, off_d1, off_d2, off_terms, off_ops, off_ddesc, off_xdesc, off_pairs;
+    int64_t total_bytes;
+};
+
+// host-side result of compiling a circuit for engine 2
+struct RegProgram {
+    RegHeader hdr;
+    std::vector<ElemGate> elems;
+    std::vector<UEntry> uent;
+    std::vector<D1Entry> d1;
+    std::vector<D2Entry> d2;
+    std::vector<ElemGate> terms;
+    std::vector<RegOp> ops;
+    std::vector<DDesc> ddesc;
+    std::vector<XDesc> xdesc;
+    std::vector<PairRef> pairs;
+    std::vector<char> blob;  // header + arrays, as uploaded
+    size_t lds_bytes = 0;
+    int n_dense_gates = 0, n_xpose = 0, n_diag = 0;
+};
+
+// Returns nullptr-equivalent (false) when the circuit is outside what engine 2
+// handles (n < kRegBits, too many thread bits, tables that do not fit LDS);
+// `why` then says so.
+bool reg_compile(int n_qubits, const std::vector<vqa_op>& ops, RegProgram* out, std::string* why);
+
+}  // namespace vqa

@@ -82,6 +82,11 @@ static int circuit_device_ctx(vqa_circuit* c, int device, DeviceCtx** out) {
         if (e != hipSuccess) VQA_FAIL(VQA_ENOMEM, "hipMalloc of the op table failed: %s", hipGetErrorString(e));
         if (!c->ops.empty())
             VQA_HIP(hipMemcpy(ctx.d_ops, c->ops.data(), c->ops.size() * sizeof(vqa_op), hipMemcpyHostToDevice));
+        if (c->reg) {
+            e = hipMalloc(&ctx.reg_prog, c->reg->blob.size());
+            if (e != hipSuccess) VQA_FAIL(VQA_ENOMEM, "hipMalloc of the compiled program failed: %s", hipGetErrorString(e));
+            VQA_HIP(hipMemcpy(ctx.reg_prog, c->reg->blob.data(), c->reg->blob.size(), hipMemcpyHostToDevice));
+        }
         it = c->dev.emplace(device, ctx).first;
     }
     *out = &it->second;
@@ -115,10 +120,19 @@ static int pack_obs(const vqa_circuit* c, const vqa_obs* const* obs, int n_obs, 
 
 static int resolve_engine(const vqa_circuit* c) { return c->engine; }
 
-static int run_call(EvalCall& call) {
+static int run_call(EvalCall& call, DeviceCtx* ctx) {
     VQA_HIP(hipSetDevice(call.device));
-    switch (resolve_engine(call.c)) {
+    int engine = resolve_engine(call.c);
+    if (engine == 2) {
+        // engine 2 measures in the Z basis only; X/Y Pauli terms and wide
+        // marginals go to the gate-by-gate LDS engine (same results)
+        bool z_only = call.n_marg_bits <= 6;
+        for (int t = 0; t < call.obs.n_terms; ++t) z_only &= call.obs.x[t] == 0;
+        if (!z_only) engine = 1;
+    }
+    switch (engine) {
     case 1: return lds_engine_run(call);
+    case 2: return reg_engine_run(call, ctx->reg_prog, *call.c->reg);
     case 3: return hbm_engine_run(call);
     default: VQA_FAIL(VQA_EUNSUPPORTED, "engine %d is not available in this build", call.c->engine);
     }
@@ -212,12 +226,24 @@ int vqa_circuit_create(int n_qubits, const vqa_op* ops, int n_ops, int n_theta, 
         }
     }
     int engine = g_engine;
+    std::shared_ptr<RegProgram> reg;
+    if ((engine == 0 && n_qubits >= kRegBits && n_qubits <= 12) || engine == 2) {
+        reg = std::make_shared<RegProgram>();
+        std::string why;
+        std::vector<vqa_op> v(ops, ops + n_ops);
+        if (!reg_compile(n_qubits, v, reg.get(), &why)) {
+            if (engine == 2) VQA_FAIL(VQA_EUNSUPPORTED, "the register-blocked engine cannot run this circuit: %s", why.c_str());
+            reg.reset();
+        } else {
+            engine = 2;
+        }
+    }
     if (engine == 0) engine = n_qubits <= lds_engine_max_qubits() ? 1 : 3;
-    if (engine == 1 && n_qubits > lds_engine_max_qubits())
-        VQA_FAIL(VQA_EUNSUPPORTED, "the LDS engine holds at most %d qubits", lds_engine_max_qubits());
-    if (engine == 2) VQA_FAIL(VQA_EUNSUPPORTED, "engine 2 is not available in this build");
+    if ((engine == 1 || engine == 2) && n_qubits > lds_engine_max_qubits())
+        VQA_FAIL(VQA_EUNSUPPORTED, "the workgroup-resident engines hold at most %d qubits", lds_engine_max_qubits());
     vqa_circuit* c = new (std::nothrow) vqa_circuit();
     if (!c) VQA_FAIL(VQA_ENOMEM, "out of host memory");
+    c->reg = reg;
     c->n_qubits = n_qubits;
     c->n_ops = n_ops;
     c->n_theta = n_theta;
@@ -301,7 +327,7 @@ static int eval_dev_common(vqa_circuit* c, int device, void* stream, const doubl
     call.n_marg_bits = n_marg_bits;
     call.d_out_expect = d_out_e;
     call.d_out_marginal = d_out_m;
-    return run_call(call);
+    return run_call(call, ctx);
 }
 
 int vqa_eval_batch_dev(vqa_circuit* c, int device, void* stream, const double* d_theta,

@@ -115,9 +115,7 @@ struct vqa_obs {
     std::vector<uint64_t> z, x;
 };
 
-namespace vqa {
-struct RegProgram;  // engine 2 (kern_reg.hip)
-}
+#include "reg_program.h"
 
 struct vqa_circuit {
     int n_qubits, n_ops, n_theta, n_input;
@@ -148,6 +146,7 @@ struct EvalCall {  // one batched evaluation, all pointers on the device
 // engines: each returns VQA_OK or an error code with set_error() called
 int lds_engine_run(const EvalCall& call);
 int lds_engine_max_qubits();
+int reg_engine_run(const EvalCall& call, const void* d_prog, const RegProgram& prog);
 int hbm_engine_run(const EvalCall& call);
 int hbm_engine_statevector(const EvalCall& call, double* d_out_state);
 
