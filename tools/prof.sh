@@ -1,0 +1,13 @@
+#!/bin/bash
+# Usage (on the GPU box): tools/prof.sh <tag> <bench args...>
+# kernel-trace stats + two PMC passes for the bench command; summaries land in gpurun_out/prof_<tag>/
+set -e
+tag=$1; shift
+cd /tmp && export TMPDIR=/tmp
+out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
+mkdir -p $out
+cd $GRAFT_REPO_ROOT
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o trace -- python3 bench.py "$@" --no-cpu-baseline > $out/trace.log 2>&1
+timeout -s KILL 300 rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY -d $out/pmc1 -o pmc1 -- python3 bench.py "$@" --no-cpu-baseline > $out/pmc1.log 2>&1
+timeout -s KILL 300 rocprofv3 --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $out/pmc2 -o pmc2 -- python3 bench.py "$@" --no-cpu-baseline > $out/pmc2.log 2>&1
+find $out -name "*.csv" | head -20

@@ -305,8 +305,11 @@ bool reg_compile(int n, const std::vector<vqa_op>& gate_list, RegProgram* out, s
                     xd.wconst[p] = slot;
                 }
                 for (int p = 0; p < n; ++p) xd.rconst[p] = xd.wconst[sigma[p]];
-                emit(ROP_XPOSE, (int)P.xdesc.size(), 0);
-                P.xdesc.push_back(xd);
+                int xid = -1;
+                for (size_t k = 0; k < P.xdesc.size() && xid < 0; ++k)
+                    if (!memcmp(&P.xdesc[k], &xd, sizeof(xd))) xid = (int)k;
+                if (xid < 0) { xid = (int)P.xdesc.size(); P.xdesc.push_back(xd); }
+                emit(ROP_XPOSE, xid, 0);
                 ++P.n_xpose;
                 for (int i = 0; i < nb; ++i) emit_direct(remaining[i], uidx[u][remaining[i]]);
                 remaining.erase(remaining.begin(), remaining.begin() + nb);
@@ -333,8 +336,10 @@ bool reg_compile(int n, const std::vector<vqa_op>& gate_list, RegProgram* out, s
             P.pairs.insert(P.pairs.end(), rt.begin(), rt.end());
             dd.rr_begin = (int)P.pairs.size(); dd.rr_count = (int)rr.size();
             P.pairs.insert(P.pairs.end(), rr.begin(), rr.end());
-            dd.has_sign = (!s.cz.empty() || !s.z.empty()) ? 1 : 0;
-            if (dd.has_sign) {
+            dd.sign_id = -1;
+            if (!s.cz.empty() || !s.z.empty()) {
+                SignTab sg;
+                memset(&sg, 0, sizeof(sg));
                 for (int t = 0; t < (1 << T); ++t) {
                     int base = 0, cr[kRegBits] = { 0, 0, 0, 0 };
                     for (auto& p : s.cz) {
@@ -347,8 +352,8 @@ bool reg_compile(int n, const std::vector<vqa_op>& gate_list, RegProgram* out, s
                         const int p = pos_of[q];
                         if (p >= R) base ^= (t >> (p - R)) & 1;
                     }
-                    if (base) dd.tt_par[t >> 5] |= 1u << (t & 31);
-                    for (int j = 0; j < R; ++j) if (cr[j]) dd.cross[j][t >> 5] |= 1u << (t & 31);
+                    if (base) sg.tt_par[t >> 5] |= 1u << (t & 31);
+                    for (int j = 0; j < R; ++j) if (cr[j]) sg.cross[j][t >> 5] |= 1u << (t & 31);
                 }
                 for (int r = 0; r < kRegAmps; ++r) {
                     int b = 0;
@@ -360,8 +365,11 @@ bool reg_compile(int n, const std::vector<vqa_op>& gate_list, RegProgram* out, s
                         const int p = pos_of[q];
                         if (p < R) b ^= (r >> p) & 1;
                     }
-                    if (b) dd.rr_par |= 1u << r;
+                    if (b) sg.rr_par |= 1u << r;
                 }
+                for (size_t k = 0; k < P.signs.size() && dd.sign_id < 0; ++k)
+                    if (!memcmp(&P.signs[k], &sg, sizeof(sg))) dd.sign_id = (int)k;
+                if (dd.sign_id < 0) { dd.sign_id = (int)P.signs.size(); P.signs.push_back(sg); }
             }
             emit(ROP_DIAG, (int)P.ddesc.size(), 0);
             P.ddesc.push_back(dd);
@@ -380,11 +388,12 @@ bool reg_compile(int n, const std::vector<vqa_op>& gate_list, RegProgram* out, s
     H.n_ddesc = (int)P.ddesc.size();
     H.n_xdesc = (int)P.xdesc.size();
     H.n_pairs = (int)P.pairs.size();
+    H.n_sign = (int)P.signs.size();
     H.has_xpose = P.n_xpose > 0;
 
     const size_t tab = (size_t)H.S * ((size_t)H.n_uent + H.n_d1 + H.n_d2) * 16;
     const size_t xbuf = H.has_xpose ? ((size_t)16 << n) : 0;
-    P.lds_bytes = tab + xbuf + 64 * sizeof(double);
+    P.lds_bytes = tab + xbuf + 64 * sizeof(double) + (((size_t)H.n_sign * H.block + 15) & ~(size_t)15);
     if (P.lds_bytes > 160 * 1024) { *why = "per-evaluation tables do not fit LDS"; return false; }
 
     // ---- device blob ----
@@ -398,6 +407,7 @@ bool reg_compile(int n, const std::vector<vqa_op>& gate_list, RegProgram* out, s
     H.off_ddesc = place(P.blob, P.ddesc);
     H.off_xdesc = place(P.blob, P.xdesc);
     H.off_pairs = place(P.blob, P.pairs);
+    H.off_signs = place(P.blob, P.signs);
     while (P.blob.size() % 16) P.blob.push_back(0);
     H.total_bytes = (int64_t)P.blob.size();
     memcpy(P.blob.data(), &H, sizeof(H));

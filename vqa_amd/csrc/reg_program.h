@@ -82,12 +82,17 @@ struct DDesc {
     int32_t tt_begin, tt_count;       // pairs with both qubits on thread bits: a, b = thread bit numbers
     int32_t rt_begin, rt_count;       // a = register bit, b = thread bit number
     int32_t rr_begin, rr_count;       // a, b = register bits
-    int32_t has_sign;                 // any CZ / Z in this stage
+    int32_t sign_id;                  // index of the stage's CZ / Z sign table, -1: no signs
     int8_t qubit_at_pos[kMaxPos];
-    uint32_t tt_par[kSignWords];      // bit t: sign parity from thread-only CZ/Z terms
+};
+
+// CZ / Z signs of a D-stage in a given layout: sign(r, t) = tt_par[t] ^
+// XOR_j (r_j & cross[j][t]) ^ rr_par[r].  Identical tables are shared.
+struct SignTab {
+    uint32_t tt_par[kSignWords];           // bit t: parity from thread-only terms
     uint32_t cross[kRegBits][kSignWords];  // bit t: parity flip when register bit j is set
-    uint32_t rr_par;                  // bit r: parity from register-only CZ/Z terms
-    int32_t pad;
+    uint32_t rr_par;                       // bit r: parity from register-only terms
+    int32_t pad[3];
 };
 
 // LDS transposition: slot(index) is XOR-linear; wconst[p] = slot of old-layout
@@ -102,11 +107,11 @@ struct RegHeader {
     int32_t block;               // threads per workgroup
     int32_t S;                   // states per workgroup
     int32_t n_uent, n_d1, n_d2;  // per-evaluation table sizes (entries of 16 bytes)
-    int32_t n_elems, n_terms, n_ops, n_ddesc, n_xdesc, n_pairs;
+    int32_t n_elems, n_terms, n_ops, n_ddesc, n_xdesc, n_pairs, n_sign;
     int32_t has_xpose;
     int8_t final_qubit_at_pos[kMaxPos];
     // byte offsets of the arrays inside the device blob
-    int64_t off_elems, off_uent, off_d1, off_d2, off_terms, off_ops, off_ddesc, off_xdesc, off_pairs;
+    int64_t off_elems, off_uent, off_d1, off_d2, off_terms, off_ops, off_ddesc, off_xdesc, off_pairs, off_signs;
     int64_t total_bytes;
 };
 
@@ -122,6 +127,7 @@ struct RegProgram {
     std::vector<DDesc> ddesc;
     std::vector<XDesc> xdesc;
     std::vector<PairRef> pairs;
+    std::vector<SignTab> signs;
     std::vector<char> blob;  // header + arrays, as uploaded
     size_t lds_bytes = 0;
     int n_dense_gates = 0, n_xpose = 0, n_diag = 0;
