@@ -193,9 +193,14 @@ int64_t place(std::vector<char>& blob, const std::vector<T>& v) {
     return off;
 }
 
+struct Layout {
+    int q_at[kMaxPos], pos_of[kMaxPos];
+};
+
 }  // namespace
 
-bool reg_compile(int n, const std::vector<vqa_op>& gate_list, RegProgram* out, std::string* why) {
+bool reg_compile(int n, int n_theta, const std::vector<vqa_op>& gate_list, RegProgram* out,
+                 std::string* why) {
     const int R = kRegBits;
     if (n < R) { *why = "fewer qubits than register bits"; return false; }
     const int T = n - R;
@@ -216,31 +221,109 @@ bool reg_compile(int n, const std::vector<vqa_op>& gate_list, RegProgram* out, s
     const int NU = (int)ustages.size(), ND = (int)dstages.size();
     if (NU > 0 && ND != NU - 1) { *why = "internal: stages do not alternate"; return false; }
 
-    // ---- per-evaluation tables ----
-    // ph1: D-stage d, qubit q -> index d*n + q
+    // ---- U-entries (tables indexed by entry; phase slots are assigned after scheduling) ----
     std::vector<std::map<int, int>> uidx(NU);  // U-stage -> qubit -> U-entry index
     for (int u = 0; u < NU; ++u) {
         for (auto& kv : st[ustages[u]].g) {
             UEntry e;
+            memset(&e, 0, sizeof(e));
             e.begin = (int)P.elems.size();
             e.count = (int)kv.second.size();
             P.elems.insert(P.elems.end(), kv.second.begin(), kv.second.end());
-            e.d_before = u > 0 ? (u - 1) * n + kv.first : -1;
-            e.d_after = u < NU - 1 ? u * n + kv.first : -1;
+            e.d_before = e.d_after = -1;
             e.parity = u & 1;
-            e.pad = 0;
             uidx[u][kv.first] = (int)P.uent.size();
             P.uent.push_back(e);
             ++P.n_dense_gates;
         }
     }
+
+    // ---- schedule: ops + the layout every D-stage is applied in ----
+    Layout lay;
+    for (int p = 0; p < kMaxPos; ++p) { lay.q_at[p] = p < n ? p : -1; lay.pos_of[p] = p; }
+    std::vector<Layout> dlayout(ND);
+    auto emit = [&](int kind, int a, int b) { P.ops.push_back(RegOp{ kind, a, b, 0 }); };
+    auto emit_direct = [&](int q, int ue) {
+        const int p = lay.pos_of[q];
+        if (p < R) emit(ROP_UREG, p, ue);
+        else emit(ROP_ULANE, p - R, ue);
+    };
+    auto cheap = [&](int p) { return p < R || p == R + 0 || p == R + 1 || p == R + 3; };
+    const int cheap_slots[7] = { 0, 1, 2, 3, R + 0, R + 1, R + 3 };
+
+    for (int u = 0; u < NU; ++u) {
+        std::vector<std::pair<int, int>> byq;  // (position, qubit)
+        for (auto& kv : uidx[u]) byq.push_back({ lay.pos_of[kv.first], kv.first });
+        std::sort(byq.begin(), byq.end());
+        if (W == 0) {
+            for (auto& pq : byq) emit_direct(pq.second, uidx[u][pq.second]);
+        } else {
+            std::vector<int> remaining;
+            for (auto& pq : byq) {
+                if (cheap(pq.first)) emit_direct(pq.second, uidx[u][pq.second]);
+                else remaining.push_back(pq.second);
+            }
+            while (!remaining.empty()) {
+                bool any_wave = false;
+                for (int q : remaining) any_wave |= lay.pos_of[q] >= R + L;
+                if (!any_wave && remaining.size() <= 1) {
+                    for (int q : remaining) emit_direct(q, uidx[u][q]);
+                    break;
+                }
+                const int nb = (int)std::min<size_t>(7, remaining.size());
+                int old_pos_of[kMaxPos];
+                memcpy(old_pos_of, lay.pos_of, sizeof(old_pos_of));
+                for (int i = 0; i < nb; ++i) {
+                    const int qa = remaining[i], pa = lay.pos_of[qa], pb = cheap_slots[i], qb = lay.q_at[pb];
+                    lay.q_at[pa] = qb; lay.pos_of[qb] = pa;
+                    lay.q_at[pb] = qa; lay.pos_of[qa] = pb;
+                }
+                int sigma[kMaxPos];
+                for (int p = 0; p < n; ++p) sigma[p] = old_pos_of[lay.q_at[p]];
+                std::vector<uint32_t> f = find_swizzle(n, sigma);
+                XDesc xd;
+                memset(&xd, 0, sizeof(xd));
+                for (int p = 0; p < n; ++p) {
+                    int slot = 0;
+                    for (int k = 0; k < n; ++k) slot |= (int)((f[k] >> p) & 1) << k;
+                    xd.wconst[p] = slot << 4;  // byte offset of a 16-byte slot
+                }
+                for (int p = 0; p < n; ++p) xd.rconst[p] = xd.wconst[sigma[p]];
+                int xid = -1;
+                for (size_t k = 0; k < P.xdesc.size() && xid < 0; ++k)
+                    if (!memcmp(&P.xdesc[k], &xd, sizeof(xd))) xid = (int)k;
+                if (xid < 0) { xid = (int)P.xdesc.size(); P.xdesc.push_back(xd); }
+                emit(ROP_XPOSE, xid, 0);
+                ++P.n_xpose;
+                for (int i = 0; i < nb; ++i) emit_direct(remaining[i], uidx[u][remaining[i]]);
+                remaining.erase(remaining.begin(), remaining.begin() + nb);
+            }
+        }
+        if (u < NU - 1) {
+            dlayout[u] = lay;
+            emit(ROP_DIAG, u, 0);
+            ++P.n_diag;
+        }
+    }
+    emit(ROP_END, 0, 0);
+    for (int p = 0; p < kMaxPos; ++p) H.final_qubit_at_pos[p] = (int8_t)(p < n ? lay.q_at[p] : -1);
+
+    // ---- phase tables: slot = stage * n + POSITION in that stage's layout ----
+    for (int u = 0; u < NU; ++u) {
+        for (auto& kv : uidx[u]) {
+            UEntry& e = P.uent[kv.second];
+            if (u > 0) e.d_before = (u - 1) * n + dlayout[u - 1].pos_of[kv.first];
+            if (u < NU - 1) e.d_after = u * n + dlayout[u].pos_of[kv.first];
+        }
+    }
     std::vector<std::map<std::pair<int, int>, int>> d2idx(ND);
     for (int d = 0; d < ND; ++d) {
         const Stage& s = st[dstages[d]];
-        for (int q = 0; q < n; ++q) {
+        const Layout& ly = dlayout[d];
+        for (int p = 0; p < n; ++p) {
             D1Entry e;
             e.begin = (int)P.terms.size();
-            auto it = s.rz.find(q);
+            auto it = s.rz.find(ly.q_at[p]);
             if (it != s.rz.end()) P.terms.insert(P.terms.end(), it->second.begin(), it->second.end());
             e.count = (int)P.terms.size() - e.begin;
             P.d1.push_back(e);
@@ -255,129 +338,121 @@ bool reg_compile(int n, const std::vector<vqa_op>& gate_list, RegProgram* out, s
         }
     }
 
-    // ---- schedule ----
-    int q_at[kMaxPos], pos_of[kMaxPos];
-    for (int p = 0; p < kMaxPos; ++p) { q_at[p] = p < n ? p : -1; pos_of[p] = p; }
-    auto emit = [&](int kind, int a, int b) { P.ops.push_back(RegOp{ kind, a, b, 0 }); };
-    auto emit_direct = [&](int q, int ue) {
-        const int p = pos_of[q];
-        if (p < R) emit(ROP_UREG, p, ue);
-        else emit(ROP_ULANE, p - R, ue);
-    };
-    auto cheap = [&](int p) { return p < R || p == R + 0 || p == R + 1 || p == R + 3; };
-    const int cheap_slots[7] = { 0, 1, 2, 3, R + 0, R + 1, R + 3 };
-
-    for (int u = 0; u < NU; ++u) {
-        std::vector<std::pair<int, int>> byq;  // (position, qubit)
-        for (auto& kv : uidx[u]) byq.push_back({ pos_of[kv.first], kv.first });
-        std::sort(byq.begin(), byq.end());
-        if (W == 0) {
-            for (auto& pq : byq) emit_direct(pq.second, uidx[u][pq.second]);
-        } else {
-            std::vector<int> remaining;
-            for (auto& pq : byq) {
-                if (cheap(pq.first)) emit_direct(pq.second, uidx[u][pq.second]);
-                else remaining.push_back(pq.second);
+    // ---- D-stage descriptors ----
+    for (int d = 0; d < ND; ++d) {
+        const Stage& s = st[dstages[d]];
+        const Layout& ly = dlayout[d];
+        DDesc dd;
+        memset(&dd, 0, sizeof(dd));
+        dd.ph1_base = d * n;
+        std::vector<PairRef> tt, rt, rr;
+        for (auto& kv : s.zz) {
+            int pa = ly.pos_of[kv.first.first], pb = ly.pos_of[kv.first.second];
+            if (pa > pb) std::swap(pa, pb);
+            const int id = d2idx[d][kv.first];
+            if (pa >= R) tt.push_back(PairRef{ pa - R, pb - R, id, 0 });
+            else if (pb >= R) rt.push_back(PairRef{ pa, pb - R, id, 0 });
+            else rr.push_back(PairRef{ pa, pb, id, 0 });
+        }
+        dd.tt_begin = (int)P.pairs.size(); dd.tt_count = (int)tt.size();
+        P.pairs.insert(P.pairs.end(), tt.begin(), tt.end());
+        dd.rt_begin = (int)P.pairs.size(); dd.rt_count = (int)rt.size();
+        P.pairs.insert(P.pairs.end(), rt.begin(), rt.end());
+        dd.rr_begin = (int)P.pairs.size(); dd.rr_count = (int)rr.size();
+        P.pairs.insert(P.pairs.end(), rr.begin(), rr.end());
+        dd.sign_id = -1;
+        if (!s.cz.empty() || !s.z.empty()) {
+            SignTab sg;
+            memset(&sg, 0, sizeof(sg));
+            for (int t = 0; t < (1 << T); ++t) {
+                int base = 0, cr[kRegBits] = { 0, 0, 0, 0 };
+                for (auto& p : s.cz) {
+                    int pa = ly.pos_of[p.first], pb = ly.pos_of[p.second];
+                    if (pa > pb) std::swap(pa, pb);
+                    if (pa >= R) base ^= (t >> (pa - R)) & (t >> (pb - R)) & 1;
+                    else if (pb >= R) cr[pa] ^= (t >> (pb - R)) & 1;
+                }
+                for (int q : s.z) {
+                    const int p = ly.pos_of[q];
+                    if (p >= R) base ^= (t >> (p - R)) & 1;
+                }
+                if (base) sg.tt_par[t >> 5] |= 1u << (t & 31);
+                for (int j = 0; j < R; ++j) if (cr[j]) sg.cross[j][t >> 5] |= 1u << (t & 31);
             }
-            while (!remaining.empty()) {
-                bool any_wave = false;
-                for (int q : remaining) any_wave |= pos_of[q] >= R + L;
-                if (!any_wave && remaining.size() <= 1) {
-                    for (int q : remaining) emit_direct(q, uidx[u][q]);
-                    break;
+            for (int r = 0; r < kRegAmps; ++r) {
+                int b = 0;
+                for (auto& p : s.cz) {
+                    const int pa = ly.pos_of[p.first], pb = ly.pos_of[p.second];
+                    if (pa < R && pb < R) b ^= (r >> pa) & (r >> pb) & 1;
                 }
-                const int nb = (int)std::min<size_t>(7, remaining.size());
-                int old_pos_of[kMaxPos];
-                memcpy(old_pos_of, pos_of, sizeof(pos_of));
-                for (int i = 0; i < nb; ++i) {
-                    const int qa = remaining[i], pa = pos_of[qa], pb = cheap_slots[i], qb = q_at[pb];
-                    q_at[pa] = qb; pos_of[qb] = pa;
-                    q_at[pb] = qa; pos_of[qa] = pb;
+                for (int q : s.z) {
+                    const int p = ly.pos_of[q];
+                    if (p < R) b ^= (r >> p) & 1;
                 }
-                int sigma[kMaxPos];
-                for (int p = 0; p < n; ++p) sigma[p] = old_pos_of[q_at[p]];
-                std::vector<uint32_t> f = find_swizzle(n, sigma);
-                XDesc xd;
-                memset(&xd, 0, sizeof(xd));
-                for (int p = 0; p < n; ++p) {
-                    int slot = 0;
-                    for (int k = 0; k < n; ++k) slot |= (int)((f[k] >> p) & 1) << k;
-                    xd.wconst[p] = slot;
+                if (b) sg.rr_par |= 1u << r;
+            }
+            for (size_t k = 0; k < P.signs.size() && dd.sign_id < 0; ++k)
+                if (!memcmp(&P.signs[k], &sg, sizeof(sg))) dd.sign_id = (int)k;
+            if (dd.sign_id < 0) { dd.sign_id = (int)P.signs.size(); P.signs.push_back(sg); }
+        }
+        P.ddesc.push_back(dd);
+    }
+    for (size_t pc = 0; pc < P.ops.size(); ++pc)
+        if (P.ops[pc].kind == ROP_DIAG) P.ddesc[P.ops[pc].a].pc = (int)pc;
+
+    // ---- what each trainable parameter touches (parameter-shift sweeps) ----
+    P.params.resize(n_theta);
+    {
+        std::vector<std::vector<PatchRef>> per(n_theta);
+        std::vector<int> first_stage(n_theta, 1 << 30);  // 2u for U-stage u, 2d+1 for D-stage d
+        for (int u = 0; u < NU; ++u) {
+            for (auto& kv : uidx[u]) {
+                const UEntry& e = P.uent[kv.second];
+                std::vector<int> seen;
+                for (int j = 0; j < e.count; ++j) {
+                    const ElemGate& g = P.elems[e.begin + j];
+                    if (g.src != VQA_SRC_THETA) continue;
+                    if (std::find(seen.begin(), seen.end(), g.idx) != seen.end()) continue;
+                    seen.push_back(g.idx);
+                    per[g.idx].push_back(PatchRef{ 0, kv.second, 0.0 });
+                    first_stage[g.idx] = std::min(first_stage[g.idx], 2 * u);
                 }
-                for (int p = 0; p < n; ++p) xd.rconst[p] = xd.wconst[sigma[p]];
-                int xid = -1;
-                for (size_t k = 0; k < P.xdesc.size() && xid < 0; ++k)
-                    if (!memcmp(&P.xdesc[k], &xd, sizeof(xd))) xid = (int)k;
-                if (xid < 0) { xid = (int)P.xdesc.size(); P.xdesc.push_back(xd); }
-                emit(ROP_XPOSE, xid, 0);
-                ++P.n_xpose;
-                for (int i = 0; i < nb; ++i) emit_direct(remaining[i], uidx[u][remaining[i]]);
-                remaining.erase(remaining.begin(), remaining.begin() + nb);
             }
         }
-        if (u < NU - 1) {
-            const Stage& s = st[dstages[u]];
-            DDesc dd;
-            memset(&dd, 0, sizeof(dd));
-            dd.ph1_base = u * n;
-            for (int p = 0; p < kMaxPos; ++p) dd.qubit_at_pos[p] = (int8_t)(p < n ? q_at[p] : -1);
-            std::vector<PairRef> tt, rt, rr;
-            for (auto& kv : s.zz) {
-                int pa = pos_of[kv.first.first], pb = pos_of[kv.first.second];
-                if (pa > pb) std::swap(pa, pb);
-                const int id = d2idx[u][kv.first];
-                if (pa >= R) tt.push_back(PairRef{ pa - R, pb - R, id, 0 });
-                else if (pb >= R) rt.push_back(PairRef{ pa, pb - R, id, 0 });
-                else rr.push_back(PairRef{ pa, pb, id, 0 });
-            }
-            dd.tt_begin = (int)P.pairs.size(); dd.tt_count = (int)tt.size();
-            P.pairs.insert(P.pairs.end(), tt.begin(), tt.end());
-            dd.rt_begin = (int)P.pairs.size(); dd.rt_count = (int)rt.size();
-            P.pairs.insert(P.pairs.end(), rt.begin(), rt.end());
-            dd.rr_begin = (int)P.pairs.size(); dd.rr_count = (int)rr.size();
-            P.pairs.insert(P.pairs.end(), rr.begin(), rr.end());
-            dd.sign_id = -1;
-            if (!s.cz.empty() || !s.z.empty()) {
-                SignTab sg;
-                memset(&sg, 0, sizeof(sg));
-                for (int t = 0; t < (1 << T); ++t) {
-                    int base = 0, cr[kRegBits] = { 0, 0, 0, 0 };
-                    for (auto& p : s.cz) {
-                        int pa = pos_of[p.first], pb = pos_of[p.second];
-                        if (pa > pb) std::swap(pa, pb);
-                        if (pa >= R) base ^= (t >> (pa - R)) & (t >> (pb - R)) & 1;
-                        else if (pb >= R) cr[pa] ^= (t >> (pb - R)) & 1;
-                    }
-                    for (int q : s.z) {
-                        const int p = pos_of[q];
-                        if (p >= R) base ^= (t >> (p - R)) & 1;
-                    }
-                    if (base) sg.tt_par[t >> 5] |= 1u << (t & 31);
-                    for (int j = 0; j < R; ++j) if (cr[j]) sg.cross[j][t >> 5] |= 1u << (t & 31);
+        for (int d = 0; d < ND; ++d) {
+            auto scan = [&](int kind, int index, int begin, int count) {
+                std::map<int, double> sums;
+                for (int j = 0; j < count; ++j) {
+                    const ElemGate& g = P.terms[begin + j];
+                    if (g.src == VQA_SRC_THETA) sums[g.idx] += g.coef;
                 }
-                for (int r = 0; r < kRegAmps; ++r) {
-                    int b = 0;
-                    for (auto& p : s.cz) {
-                        const int pa = pos_of[p.first], pb = pos_of[p.second];
-                        if (pa < R && pb < R) b ^= (r >> pa) & (r >> pb) & 1;
-                    }
-                    for (int q : s.z) {
-                        const int p = pos_of[q];
-                        if (p < R) b ^= (r >> p) & 1;
-                    }
-                    if (b) sg.rr_par |= 1u << r;
+                for (auto& kv : sums) {
+                    per[kv.first].push_back(PatchRef{ kind, index, kv.second });
+                    first_stage[kv.first] = std::min(first_stage[kv.first], 2 * d + 1);
                 }
-                for (size_t k = 0; k < P.signs.size() && dd.sign_id < 0; ++k)
-                    if (!memcmp(&P.signs[k], &sg, sizeof(sg))) dd.sign_id = (int)k;
-                if (dd.sign_id < 0) { dd.sign_id = (int)P.signs.size(); P.signs.push_back(sg); }
+            };
+            for (int p = 0; p < n; ++p) scan(1, d * n + p, P.d1[d * n + p].begin, P.d1[d * n + p].count);
+            for (auto& kv : d2idx[d]) scan(2, kv.second, P.d2[kv.second].begin, P.d2[kv.second].count);
+        }
+        for (int i = 0; i < n_theta; ++i) {
+            ParamInfo& pi = P.params[i];
+            pi.ref_begin = (int)P.refs.size();
+            pi.ref_count = (int)per[i].size();
+            P.refs.insert(P.refs.end(), per[i].begin(), per[i].end());
+            // U-stage u changes the tables of D-stage u-1 (its RZ(gamma)); D-stage d its own
+            int rd;
+            if (first_stage[i] == (1 << 30)) rd = ND;             // parameter not used: nothing to redo
+            else if (first_stage[i] & 1) rd = first_stage[i] / 2;
+            else rd = first_stage[i] / 2 - 1;
+            if (rd >= ND) {            // only the last U-stage (or nothing) changes
+                pi.resume_diag = ND > 0 ? ND - 1 : -1;
+                if (first_stage[i] != (1 << 30) && ND == 0) pi.resume_diag = -1;
+            } else {
+                pi.resume_diag = rd;   // -1: the first U-stage changes -> restart
             }
-            emit(ROP_DIAG, (int)P.ddesc.size(), 0);
-            P.ddesc.push_back(dd);
-            ++P.n_diag;
+            pi.resume_pc = pi.resume_diag >= 0 ? P.ddesc[pi.resume_diag].pc : 0;
         }
     }
-    emit(ROP_END, 0, 0);
-    for (int p = 0; p < kMaxPos; ++p) H.final_qubit_at_pos[p] = (int8_t)(p < n ? q_at[p] : -1);
 
     H.n_uent = (int)P.uent.size();
     H.n_d1 = (int)P.d1.size();
@@ -389,11 +464,15 @@ bool reg_compile(int n, const std::vector<vqa_op>& gate_list, RegProgram* out, s
     H.n_xdesc = (int)P.xdesc.size();
     H.n_pairs = (int)P.pairs.size();
     H.n_sign = (int)P.signs.size();
+    H.n_params = n_theta;
+    H.n_refs = (int)P.refs.size();
     H.has_xpose = P.n_xpose > 0;
 
-    const size_t tab = (size_t)H.S * ((size_t)H.n_uent + H.n_d1 + H.n_d2) * 16;
+    const size_t tab1 = ((size_t)H.n_uent + H.n_d1 + H.n_d2) * 16;
     const size_t xbuf = H.has_xpose ? ((size_t)16 << n) : 0;
-    P.lds_bytes = tab + xbuf + 64 * sizeof(double) + (((size_t)H.n_sign * H.block + 15) & ~(size_t)15);
+    const size_t fixed = 64 * sizeof(double) + (((size_t)H.n_sign * H.block * 2 + 15) & ~(size_t)15);
+    P.lds_bytes = (size_t)H.S * tab1 + xbuf + fixed;
+    P.lds_bytes_psr = tab1 + xbuf + fixed + 16 * 16;
     if (P.lds_bytes > 160 * 1024) { *why = "per-evaluation tables do not fit LDS"; return false; }
 
     // ---- device blob ----
@@ -408,6 +487,8 @@ bool reg_compile(int n, const std::vector<vqa_op>& gate_list, RegProgram* out, s
     H.off_xdesc = place(P.blob, P.xdesc);
     H.off_pairs = place(P.blob, P.pairs);
     H.off_signs = place(P.blob, P.signs);
+    H.off_params = place(P.blob, P.params);
+    H.off_refs = place(P.blob, P.refs);
     while (P.blob.size() % 16) P.blob.push_back(0);
     H.total_bytes = (int64_t)P.blob.size();
     memcpy(P.blob.data(), &H, sizeof(H));

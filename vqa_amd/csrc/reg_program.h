@@ -1,5 +1,5 @@
 // Program format of engine 2 (register-blocked fused engine), shared by the
-// host-side circuit compiler (reg_compile.cpp) and the kernel (kern_reg.hip).
+// host-side circuit compiler (reg_compile.cpp) and the kernels (kern_reg.hip).
 //
 // A circuit is brought into a normal form of alternating stages:
 //   U-stage: at most one 2x2 unitary per qubit (the product of the elementary
@@ -55,13 +55,15 @@ struct ElemGate {
 // one (U-stage, qubit): product of elems[begin, begin+count) in time order
 struct UEntry {
     int32_t begin, count;
-    int32_t d_before;  // ph1 index that absorbs e^{i gamma/2} (-1: dropped)
-    int32_t d_after;   // ph1 index that absorbs e^{i alpha/2} (-1: dropped)
-    int32_t parity;    // U-stage index & 1 (the two prep phases)
+    int32_t d_before;  // ph1 slot that absorbs e^{i gamma/2} (-1: dropped)
+    int32_t d_after;   // ph1 slot that absorbs e^{i alpha/2} (-1: dropped)
+    int32_t parity;    // U-stage index & 1 (the two preparation phases)
     int32_t pad;
 };
 
-// one single-qubit phase of a D-stage: exp(+i/2 * sum of angle terms) on |0>, conj on |1>
+// one single-qubit phase slot of a D-stage: exp(+i/2 * sum of angle terms) on
+// |0>, conj on |1>.  Slots of a stage are ordered by POSITION in the layout the
+// stage is applied in: slot = stage * n + position.
 struct D1Entry {
     int32_t begin, count;  // into terms[]
 };
@@ -78,12 +80,13 @@ struct PairRef {
 
 // a D-stage as applied in the layout current at that point of the program
 struct DDesc {
-    int32_t ph1_base;                 // ph1 index of qubit 0 of this stage (n consecutive entries)
+    int32_t ph1_base;                 // first ph1 slot of this stage (n consecutive slots, by position)
     int32_t tt_begin, tt_count;       // pairs with both qubits on thread bits: a, b = thread bit numbers
     int32_t rt_begin, rt_count;       // a = register bit, b = thread bit number
     int32_t rr_begin, rr_count;       // a, b = register bits
     int32_t sign_id;                  // index of the stage's CZ / Z sign table, -1: no signs
-    int8_t qubit_at_pos[kMaxPos];
+    int32_t pc;                       // index of the ROP_DIAG op that applies it
+    int32_t pad[3];
 };
 
 // CZ / Z signs of a D-stage in a given layout: sign(r, t) = tt_par[t] ^
@@ -95,23 +98,39 @@ struct SignTab {
     int32_t pad[3];
 };
 
-// LDS transposition: slot(index) is XOR-linear; wconst[p] = slot of old-layout
-// position bit p, rconst[p] = slot of the old position that new position p reads.
+// LDS transposition: the slot function is XOR-linear; wconst[p] = byte offset
+// contributed by old-layout position bit p, rconst[p] = byte offset of the old
+// position that new position p reads.
 struct XDesc {
     int32_t wconst[kMaxPos];
     int32_t rconst[kMaxPos];
 };
 
+// What has to be recomputed when one trainable parameter is shifted
+// (parameter-shift sweeps recompute only this and resume from a checkpoint).
+struct PatchRef {
+    int32_t kind;     // 0: U-entry `index`; 1: ph1 slot `index`; 2: ph2 entry `index`
+    int32_t index;
+    double coef_sum;  // kinds 1, 2: sum of the coefficients the parameter enters the slot with
+};
+struct ParamInfo {
+    int32_t ref_begin, ref_count;  // into refs[]
+    int32_t resume_diag;           // first D-stage whose tables change; -1: restart from |0...0>
+    int32_t resume_pc;             // op index to resume at (0 when restarting)
+};
+
 struct RegHeader {
     int32_t n, T, L, W;          // qubits, thread bits, lane bits, wave bits
     int32_t block;               // threads per workgroup
-    int32_t S;                   // states per workgroup
+    int32_t S;                   // states per workgroup (explicit-list kernel)
     int32_t n_uent, n_d1, n_d2;  // per-evaluation table sizes (entries of 16 bytes)
-    int32_t n_elems, n_terms, n_ops, n_ddesc, n_xdesc, n_pairs, n_sign;
+    int32_t n_elems, n_terms, n_ops, n_ddesc, n_xdesc, n_pairs, n_sign, n_params, n_refs;
     int32_t has_xpose;
+    int32_t pad;
     int8_t final_qubit_at_pos[kMaxPos];
     // byte offsets of the arrays inside the device blob
-    int64_t off_elems, off_uent, off_d1, off_d2, off_terms, off_ops, off_ddesc, off_xdesc, off_pairs, off_signs;
+    int64_t off_elems, off_uent, off_d1, off_d2, off_terms, off_ops, off_ddesc, off_xdesc, off_pairs,
+        off_signs, off_params, off_refs;
     int64_t total_bytes;
 };
 
@@ -128,14 +147,17 @@ struct RegProgram {
     std::vector<XDesc> xdesc;
     std::vector<PairRef> pairs;
     std::vector<SignTab> signs;
+    std::vector<ParamInfo> params;
+    std::vector<PatchRef> refs;
     std::vector<char> blob;  // header + arrays, as uploaded
-    size_t lds_bytes = 0;
+    size_t lds_bytes = 0;      // explicit-list kernel (S states per workgroup)
+    size_t lds_bytes_psr = 0;  // parameter-shift kernel (one state per workgroup)
     int n_dense_gates = 0, n_xpose = 0, n_diag = 0;
 };
 
-// Returns nullptr-equivalent (false) when the circuit is outside what engine 2
-// handles (n < kRegBits, too many thread bits, tables that do not fit LDS);
-// `why` then says so.
-bool reg_compile(int n_qubits, const std::vector<vqa_op>& ops, RegProgram* out, std::string* why);
+// Returns false when the circuit is outside what engine 2 handles (n <
+// kRegBits, too many thread bits, tables that do not fit LDS); `why` says so.
+bool reg_compile(int n_qubits, int n_theta, const std::vector<vqa_op>& ops, RegProgram* out,
+                 std::string* why);
 
 }  // namespace vqa

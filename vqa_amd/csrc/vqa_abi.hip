@@ -132,7 +132,10 @@ static int run_call(EvalCall& call, DeviceCtx* ctx) {
     }
     switch (engine) {
     case 1: return lds_engine_run(call);
-    case 2: return reg_engine_run(call, ctx->reg_prog, *call.c->reg);
+    case 2:
+        if (call.spec.psr && call.n_sweep > 0 && reg_engine_can_sweep(*call.c->reg))
+            return reg_engine_sweep(call, ctx->reg_prog, *call.c->reg, call.n_sweep);
+        return reg_engine_run(call, ctx->reg_prog, *call.c->reg);
     case 3: return hbm_engine_run(call);
     default: VQA_FAIL(VQA_EUNSUPPORTED, "engine %d is not available in this build", call.c->engine);
     }
@@ -231,7 +234,7 @@ int vqa_circuit_create(int n_qubits, const vqa_op* ops, int n_ops, int n_theta, 
         reg = std::make_shared<RegProgram>();
         std::string why;
         std::vector<vqa_op> v(ops, ops + n_ops);
-        if (!reg_compile(n_qubits, v, reg.get(), &why)) {
+        if (!reg_compile(n_qubits, n_theta, v, reg.get(), &why)) {
             if (engine == 2) VQA_FAIL(VQA_EUNSUPPORTED, "the register-blocked engine cannot run this circuit: %s", why.c_str());
             reg.reset();
         } else {
@@ -325,6 +328,7 @@ static int eval_dev_common(vqa_circuit* c, int device, void* stream, const doubl
     call.spec = spec;
     call.E = E;
     call.n_marg_bits = n_marg_bits;
+    call.n_sweep = spec.psr ? (int)(E / (2 * (int64_t)c->n_theta + 1)) : 0;
     call.d_out_expect = d_out_e;
     call.d_out_marginal = d_out_m;
     return run_call(call, ctx);
@@ -468,6 +472,7 @@ int vqa_statevector(vqa_circuit* c, int device, const double* theta, const doubl
     call.E = 1;
     memset(&call.obs, 0, sizeof(call.obs));
     call.n_marg_bits = 0;
+    call.n_sweep = 0;
     call.d_out_expect = nullptr;
     call.d_out_marginal = nullptr;
     rc = hbm_engine_statevector(call, (double*)dst.p);

@@ -139,6 +139,7 @@ struct EvalCall {  // one batched evaluation, all pointers on the device
     int64_t E;
     ObsPack obs;
     int n_marg_bits;
+    int n_sweep;  // > 0: the instance list is a full parameter-shift sweep over this many samples
     double* d_out_expect;
     double* d_out_marginal;
 };
@@ -147,6 +148,8 @@ struct EvalCall {  // one batched evaluation, all pointers on the device
 int lds_engine_run(const EvalCall& call);
 int lds_engine_max_qubits();
 int reg_engine_run(const EvalCall& call, const void* d_prog, const RegProgram& prog);
+bool reg_engine_can_sweep(const RegProgram& prog);
+int reg_engine_sweep(const EvalCall& call, const void* d_prog, const RegProgram& prog, int n_samples);
 int hbm_engine_run(const EvalCall& call);
 int hbm_engine_statevector(const EvalCall& call, double* d_out_state);
 
