@@ -16,7 +16,7 @@ for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=T
         acc[k][row["Counter_Name"]] += float(row["Counter_Value"])
         meta[k] = (row.get("VGPR_Count"), row.get("SGPR_Count"), row.get("LDS_Block_Size"), row.get("Scratch_Size"), row.get("Grid_Size"), row.get("Workgroup_Size"))
     for k, v in acc.items():
-        if "reg_eval" in k or "lds_eval" in k or len(acc) < 4:
+        if "k_reg" in k or "lds_eval" in k or "k_hbm" in k or len(acc) < 4:
             print("  ", k, "vgpr/sgpr/lds/scratch/grid/wg=", meta[k])
             for c, val in sorted(v.items()):
                 print("      %-28s %.4g" % (c, val))

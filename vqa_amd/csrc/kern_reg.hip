@@ -78,7 +78,7 @@ struct Prog {
     const VQA_CAS D1Entry* d1;
     const VQA_CAS D2Entry* d2;
     const VQA_CAS ElemGate* terms;
-    const VQA_CAS RegOp* ops;
+    const VQA_CAS PhaseOp* phases;
     const VQA_CAS DDesc* ddesc;
     const VQA_CAS XDesc* xdesc;
     const VQA_CAS PairRef* pairs;
@@ -95,7 +95,7 @@ __device__ __forceinline__ Prog load_prog(const char* blob) {
     p.d1 = to_const<D1Entry>(blob + p.H->off_d1);
     p.d2 = to_const<D2Entry>(blob + p.H->off_d2);
     p.terms = to_const<ElemGate>(blob + p.H->off_terms);
-    p.ops = to_const<RegOp>(blob + p.H->off_ops);
+    p.phases = to_const<PhaseOp>(blob + p.H->off_phases);
     p.ddesc = to_const<DDesc>(blob + p.H->off_ddesc);
     p.xdesc = to_const<XDesc>(blob + p.H->off_xdesc);
     p.pairs = to_const<PairRef>(blob + p.H->off_pairs);
@@ -262,15 +262,38 @@ __device__ __forceinline__ double xor_fetch(double v) {
     return __hiloint2double(hi, lo);
 }
 
+// The three amplitude updates are written as inline assembly with tied
+// operands so that they are in place by construction: behind the uniform
+// branches of the phase loop anything else makes the register allocator keep
+// a second copy of the state and move it back after every block.
+//   (a0, a1) <- (c a0 + s a1, c a1 - s a0)
+__device__ __forceinline__ void rot_pair(double& a0, double& a1, double c, double s) {
+    double t0, t1;
+    asm("v_mul_f64 %2, %5, %1\n\tv_mul_f64 %3, %5, %0\n\tv_fma_f64 %0, %4, %0, %2\n\tv_fma_f64 %1, %4, %1, -%3"
+        : "+v"(a0), "+v"(a1), "=&v"(t0), "=&v"(t1)
+        : "v"(c), "v"(s));
+}
+//   x <- c x + se p
+__device__ __forceinline__ void lane_upd(double& x, double p, double c, double se) {
+    double t;
+    asm("v_mul_f64 %1, %4, %2\n\tv_fma_f64 %0, %3, %0, %1" : "+v"(x), "=&v"(t) : "v"(p), "v"(c), "v"(se));
+}
+//   (ax + i ay) <- (ax + i ay) (tx + i ty)
+__device__ __forceinline__ void cmul_inplace(double& ax, double& ay, double tx, double ty) {
+    double t1, t2;
+    asm("v_mul_f64 %2, %1, %5\n\tv_mul_f64 %3, %1, %4\n\tv_fma_f64 %1, %0, %5, %3\n\tv_fma_f64 %0, %0, %4, -%2"
+        : "+v"(ax), "+v"(ay), "=&v"(t1), "=&v"(t2)
+        : "v"(tx), "v"(ty));
+}
+
 template <int J>
 __device__ __forceinline__ void apply_ureg(double2 (&amp)[kRegAmps], double c, double s) {
 #pragma unroll
     for (int r = 0; r < kRegAmps; ++r) {
         if (!(r & (1 << J))) {
             const int r1 = r | (1 << J);
-            const double2 a0 = amp[r], a1 = amp[r1];
-            amp[r] = make_double2(c * a0.x + s * a1.x, c * a0.y + s * a1.y);
-            amp[r1] = make_double2(c * a1.x - s * a0.x, c * a1.y - s * a0.y);
+            rot_pair(amp[r].x, amp[r1].x, c, s);
+            rot_pair(amp[r].y, amp[r1].y, c, s);
         }
     }
 }
@@ -278,11 +301,17 @@ __device__ __forceinline__ void apply_ureg(double2 (&amp)[kRegAmps], double c, d
 template <int LB>
 __device__ __forceinline__ void apply_ulane(double2 (&amp)[kRegAmps], double c, double s, int lane) {
     const double se = flip_if(s, (unsigned)(lane >> LB) & 1u);
+    // the cross-lane moves below read registers that the previous block wrote
+    // from inline assembly, which the compiler's hazard padding does not see
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 1");
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int r = 0; r < kRegAmps; ++r) {
         const double pr = xor_fetch<LB>(amp[r].x);
         const double pi = xor_fetch<LB>(amp[r].y);
-        amp[r] = make_double2(c * amp[r].x + se * pr, c * amp[r].y + se * pi);
+        lane_upd(amp[r].x, pr, c, se);
+        lane_upd(amp[r].y, pi, c, se);
     }
 }
 
@@ -297,135 +326,146 @@ struct Ctx {
     int xc_id, xc_wt, xc_rt;      // cached per-thread offsets of one transposition descriptor
 };
 
-// Runs ops[pc0 ..] to ROP_END.  When ckpt != nullptr the state in front of every
-// diagonal stage d is stored at ckpt[(d * 16 + r) * nthr + tid].
-__device__ __forceinline__ void run_ops(double2 (&amp)[kRegAmps], const Prog& pp, Ctx& cx, int pc0, double2* ckpt) {
-    const VQA_CAS RegOp* ops = pp.ops;
-    int pc = pc0;
-    int kind = ops[pc].kind, oa = ops[pc].a, ob = ops[pc].b;
-    double2 cs = make_double2(1.0, 0.0);
-    if (kind == ROP_UREG || kind == ROP_ULANE) cs = cx.mat[ob];
-    while (kind != ROP_END) {
-        // the next op and its rotation are fetched while the current one runs
-        const int nkind = ops[pc + 1].kind, na = ops[pc + 1].a, nb = ops[pc + 1].b;
-        double2 ncs = make_double2(1.0, 0.0);
-        if (nkind == ROP_UREG || nkind == ROP_ULANE) ncs = cx.mat[nb];
-        if (kind == ROP_UREG) {
-            switch (oa) {
-            case 0: apply_ureg<0>(amp, cs.x, cs.y); break;
-            case 1: apply_ureg<1>(amp, cs.x, cs.y); break;
-            case 2: apply_ureg<2>(amp, cs.x, cs.y); break;
-            default: apply_ureg<3>(amp, cs.x, cs.y); break;
-            }
-        } else if (kind == ROP_ULANE) {
-            switch (oa) {
-            case 0: apply_ulane<0>(amp, cs.x, cs.y, cx.lane); break;
-            case 1: apply_ulane<1>(amp, cs.x, cs.y, cx.lane); break;
-            case 2: apply_ulane<2>(amp, cs.x, cs.y, cx.lane); break;
-            case 3: apply_ulane<3>(amp, cs.x, cs.y, cx.lane); break;
-            case 4: apply_ulane<4>(amp, cs.x, cs.y, cx.lane); break;
-            default: apply_ulane<5>(amp, cs.x, cs.y, cx.lane); break;
-            }
-        } else if (kind == ROP_XPOSE) {
-            const VQA_CAS XDesc* xd = pp.xdesc + oa;
-            if (oa != cx.xc_id) {
-                int wt = 0, rt = 0;
-                for (int i = 0; i < cx.T; ++i) {
-                    const int m = -((cx.t >> i) & 1);
-                    wt ^= m & xd->wconst[kRegBits + i];
-                    rt ^= m & xd->rconst[kRegBits + i];
-                }
-                cx.xc_id = oa;
-                cx.xc_wt = wt;
-                cx.xc_rt = rt;
-            }
-            const int wt = cx.xc_wt, rt = cx.xc_rt;
-            const int w0 = xd->wconst[0], w1 = xd->wconst[1], w2 = xd->wconst[2], w3 = xd->wconst[3];
-            const int r0 = xd->rconst[0], r1 = xd->rconst[1], r2 = xd->rconst[2], r3 = xd->rconst[3];
+// One transposition through LDS (descriptor xid).
+__device__ __forceinline__ void do_xpose(double2 (&amp)[kRegAmps], const Prog& pp, Ctx& cx, int xid) {
+    const VQA_CAS XDesc* xd = pp.xdesc + xid;
+    if (xid != cx.xc_id) {
+        int wt = 0, rt = 0;
+        for (int i = 0; i < cx.T; ++i) {
+            const int m = -((cx.t >> i) & 1);
+            wt ^= m & xd->wconst[kRegBits + i];
+            rt ^= m & xd->rconst[kRegBits + i];
+        }
+        cx.xc_id = xid;
+        cx.xc_wt = wt;
+        cx.xc_rt = rt;
+    }
+    const int wt = cx.xc_wt, rt = cx.xc_rt;
+    const int w0 = xd->wconst[0], w1 = xd->wconst[1], w2 = xd->wconst[2], w3 = xd->wconst[3];
+    const int r0 = xd->rconst[0], r1 = xd->rconst[1], r2 = xd->rconst[2], r3 = xd->rconst[3];
 #pragma unroll
-            for (int r = 0; r < kRegAmps; ++r) {
-                const int off = wt ^ ((r & 1) ? w0 : 0) ^ ((r & 2) ? w1 : 0) ^ ((r & 4) ? w2 : 0) ^ ((r & 8) ? w3 : 0);
-                *(double2*)(cx.xbuf + off) = amp[r];
-            }
-            __syncthreads();
+    for (int r = 0; r < kRegAmps; ++r) {
+        const int off = wt ^ ((r & 1) ? w0 : 0) ^ ((r & 2) ? w1 : 0) ^ ((r & 4) ? w2 : 0) ^ ((r & 8) ? w3 : 0);
+        *(double2*)(cx.xbuf + off) = amp[r];
+    }
+    __syncthreads();
 #pragma unroll
-            for (int r = 0; r < kRegAmps; ++r) {
-                const int off = rt ^ ((r & 1) ? r0 : 0) ^ ((r & 2) ? r1 : 0) ^ ((r & 4) ? r2 : 0) ^ ((r & 8) ? r3 : 0);
-                amp[r] = *(const double2*)(cx.xbuf + off);
-            }
-            __syncthreads();
-        } else {  // ROP_DIAG
+    for (int r = 0; r < kRegAmps; ++r) {
+        const int off = rt ^ ((r & 1) ? r0 : 0) ^ ((r & 2) ? r1 : 0) ^ ((r & 4) ? r2 : 0) ^ ((r & 8) ? r3 : 0);
+        amp[r] = *(const double2*)(cx.xbuf + off);
+    }
+    __syncthreads();
+}
+
+// One diagonal stage (descriptor did).
+__device__ __forceinline__ void do_diag(double2 (&amp)[kRegAmps], const Prog& pp, const Ctx& cx, int did) {
+    const VQA_CAS DDesc* dd = pp.ddesc + did;
+    const double2* p1 = cx.ph1 + dd->ph1_base;
+    // thread-only factor
+    cplx F = { 1.0, 0.0 };
+    for (int i = 0; i < cx.T; ++i) {
+        const double2 p = p1[kRegBits + i];
+        F = cmul(F, csel_conj({ p.x, p.y }, (unsigned)(cx.t >> i) & 1u));
+    }
+    const int tt_begin = dd->tt_begin, tt_count = dd->tt_count;
+    for (int k = 0; k < tt_count; ++k) {
+        const int pa = pp.pairs[tt_begin + k].a, pb = pp.pairs[tt_begin + k].b;
+        const double2 z = cx.ph2[pp.pairs[tt_begin + k].ph2];
+        F = cmul(F, csel_conj({ z.x, z.y }, (unsigned)((cx.t >> pa) ^ (cx.t >> pb)) & 1u));
+    }
+    // effective phase of each register bit
+    cplx pj[kRegBits];
+#pragma unroll
+    for (int j = 0; j < kRegBits; ++j) {
+        const double2 p = p1[j];
+        pj[j] = { p.x, p.y };
+    }
+    const int rt_begin = dd->rt_begin, rt_count = dd->rt_count;
+    for (int k = 0; k < rt_count; ++k) {
+        const int pa = pp.pairs[rt_begin + k].a, pb = pp.pairs[rt_begin + k].b;
+        const double2 z = cx.ph2[pp.pairs[rt_begin + k].ph2];
+        const cplx ze = csel_conj({ z.x, z.y }, (unsigned)(cx.t >> pb) & 1u);
+#pragma unroll
+        for (int j = 0; j < kRegBits; ++j)
+            if (pa == j) pj[j] = cmul(pj[j], ze);
+    }
+    // phase table by doubling, T[r | 1<<j] = T[r] * conj(pj)^2: the lower 8 entries
+    // are kept, the upper 8 are formed on the fly to save registers
+    cplx tb[kRegAmps / 2];
+    tb[0] = cmul(cmul(F, cmul(pj[0], pj[1])), cmul(pj[2], pj[3]));
+#pragma unroll
+    for (int j = 0; j < kRegBits - 1; ++j) {
+        const cplx cj = cconj(pj[j]);
+        const cplx w = cmul(cj, cj);
+#pragma unroll
+        for (int r = 0; r < (1 << j); ++r) tb[r | (1 << j)] = cmul(tb[r], w);
+    }
+    const cplx c3 = cconj(pj[kRegBits - 1]);
+    const cplx w3 = cmul(c3, c3);
+    // CZ / Z signs: bit r of the thread's mask flips entry r
+    const int sign_id = dd->sign_id;
+    unsigned sm = 0;
+    if (sign_id >= 0) sm = cx.smask[sign_id * cx.nthr + cx.tid];
+#pragma unroll
+    for (int r = 0; r < kRegAmps / 2; ++r) {
+        const int flip_lo = (int)((sm << (31 - r)) & 0x80000000u);
+        const int flip_hi = (int)((sm << (31 - (r + 8))) & 0x80000000u);
+        const cplx hi = cmul(tb[r], w3);
+        cmul_inplace(amp[r].x, amp[r].y,
+                     __hiloint2double(__double2hiint(tb[r].x) ^ flip_lo, __double2loint(tb[r].x)),
+                     __hiloint2double(__double2hiint(tb[r].y) ^ flip_lo, __double2loint(tb[r].y)));
+        cmul_inplace(amp[r + 8].x, amp[r + 8].y,
+                     __hiloint2double(__double2hiint(hi.x) ^ flip_hi, __double2loint(hi.x)),
+                     __hiloint2double(__double2hiint(hi.y) ^ flip_hi, __double2loint(hi.y)));
+    }
+    // register-register ZZ phases
+    const int rr_begin = dd->rr_begin, rr_count = dd->rr_count;
+    for (int k = 0; k < rr_count; ++k) {
+        const int pa = pp.pairs[rr_begin + k].a, pb = pp.pairs[rr_begin + k].b;
+        const double2 z = cx.ph2[pp.pairs[rr_begin + k].ph2];
+#pragma unroll
+        for (int r = 0; r < kRegAmps; ++r) {
+            const cplx ze = csel_conj({ z.x, z.y }, (unsigned)((r >> pa) ^ (r >> pb)) & 1u);
+            cmul_inplace(amp[r].x, amp[r].y, ze.x, ze.y);
+        }
+    }
+}
+
+// Runs phases[p0 ..] to PH_END.  diag_only_first: the first phase starts at its
+// diagonal stage (resuming from a checkpoint taken in front of it).  When ckpt
+// != nullptr the state in front of every diagonal stage d is stored at
+// ckpt[(d * 16 + r) * nthr + tid].
+__device__ __forceinline__ void run_phases(double2 (&amp)[kRegAmps], const Prog& pp, Ctx& cx, int p0,
+                                           bool diag_only_first, double2* ckpt) {
+    const VQA_CAS PhaseOp* ph = pp.phases;
+    int first_mask = diag_only_first ? (PH_DIAG | PH_END) : -1;
+    for (int p = p0;; ++p) {
+        const int flags = ph[p].flags & first_mask;
+        first_mask = -1;
+        if (flags & PH_END) break;
+        if (flags & PH_XPOSE) do_xpose(amp, pp, cx, ph[p].xdesc);
+        // rotations: the (cos, sin) of the next slot is fetched while the current one runs
+        double2 cs = cx.mat[ph[p].ent[0]], csn;
+#define VQA_REG_SLOT(J)                                           \
+        csn = cx.mat[ph[p].ent[J + 1]];                           \
+        if (flags & (PH_UREG0 << J)) apply_ureg<J>(amp, cs.x, cs.y); \
+        cs = csn;
+        VQA_REG_SLOT(0) VQA_REG_SLOT(1) VQA_REG_SLOT(2) VQA_REG_SLOT(3)
+#undef VQA_REG_SLOT
+#define VQA_LANE_SLOT(LB)                                                  \
+        csn = cx.mat[ph[p].ent[LB + 5 < 10 ? LB + 5 : 9]];                 \
+        if (flags & (PH_ULANE0 << LB)) apply_ulane<LB>(amp, cs.x, cs.y, cx.lane); \
+        cs = csn;
+        VQA_LANE_SLOT(0) VQA_LANE_SLOT(1) VQA_LANE_SLOT(2) VQA_LANE_SLOT(3) VQA_LANE_SLOT(4) VQA_LANE_SLOT(5)
+#undef VQA_LANE_SLOT
+        if (flags & PH_DIAG) {
+            const int did = ph[p].ddesc;
             if (ckpt) {
 #pragma unroll
-                for (int r = 0; r < kRegAmps; ++r) ckpt[((size_t)oa * kRegAmps + r) * cx.nthr + cx.tid] = amp[r];
+                for (int r = 0; r < kRegAmps; ++r) ckpt[((size_t)did * kRegAmps + r) * cx.nthr + cx.tid] = amp[r];
             }
-            const VQA_CAS DDesc* dd = pp.ddesc + oa;
-            const double2* p1 = cx.ph1 + dd->ph1_base;
-            // thread-only factor
-            cplx F = { 1.0, 0.0 };
-            for (int i = 0; i < cx.T; ++i) {
-                const double2 p = p1[kRegBits + i];
-                F = cmul(F, csel_conj({ p.x, p.y }, (unsigned)(cx.t >> i) & 1u));
-            }
-            const int tt_begin = dd->tt_begin, tt_count = dd->tt_count;
-            for (int k = 0; k < tt_count; ++k) {
-                const int pa = pp.pairs[tt_begin + k].a, pb = pp.pairs[tt_begin + k].b;
-                const double2 z = cx.ph2[pp.pairs[tt_begin + k].ph2];
-                F = cmul(F, csel_conj({ z.x, z.y }, (unsigned)((cx.t >> pa) ^ (cx.t >> pb)) & 1u));
-            }
-            // effective phase of each register bit
-            cplx pj[kRegBits];
-#pragma unroll
-            for (int j = 0; j < kRegBits; ++j) {
-                const double2 p = p1[j];
-                pj[j] = { p.x, p.y };
-            }
-            const int rt_begin = dd->rt_begin, rt_count = dd->rt_count;
-            for (int k = 0; k < rt_count; ++k) {
-                const int pa = pp.pairs[rt_begin + k].a, pb = pp.pairs[rt_begin + k].b;
-                const double2 z = cx.ph2[pp.pairs[rt_begin + k].ph2];
-                const cplx ze = csel_conj({ z.x, z.y }, (unsigned)(cx.t >> pb) & 1u);
-#pragma unroll
-                for (int j = 0; j < kRegBits; ++j)
-                    if (pa == j) pj[j] = cmul(pj[j], ze);
-            }
-            // 16-entry table by doubling: T[r | 1<<j] = T[r] * conj(pj)^2
-            cplx tb[kRegAmps];
-            tb[0] = cmul(cmul(F, cmul(pj[0], pj[1])), cmul(pj[2], pj[3]));
-#pragma unroll
-            for (int j = 0; j < kRegBits; ++j) {
-                const cplx cj = cconj(pj[j]);
-                const cplx w = cmul(cj, cj);
-#pragma unroll
-                for (int r = 0; r < (1 << j); ++r) tb[r | (1 << j)] = cmul(tb[r], w);
-            }
-            // CZ / Z signs: bit r of the thread's mask flips entry r
-            const int sign_id = dd->sign_id;
-            unsigned sm = 0;
-            if (sign_id >= 0) sm = cx.smask[sign_id * cx.nthr + cx.tid];
-#pragma unroll
-            for (int r = 0; r < kRegAmps; ++r) {
-                const int flip = (int)((sm << (31 - r)) & 0x80000000u);
-                const cplx tr = { __hiloint2double(__double2hiint(tb[r].x) ^ flip, __double2loint(tb[r].x)),
-                                  __hiloint2double(__double2hiint(tb[r].y) ^ flip, __double2loint(tb[r].y)) };
-                const cplx v = cmul({ amp[r].x, amp[r].y }, tr);
-                amp[r] = make_double2(v.x, v.y);
-            }
-            // register-register ZZ phases
-            const int rr_begin = dd->rr_begin, rr_count = dd->rr_count;
-            for (int k = 0; k < rr_count; ++k) {
-                const int pa = pp.pairs[rr_begin + k].a, pb = pp.pairs[rr_begin + k].b;
-                const double2 z = cx.ph2[pp.pairs[rr_begin + k].ph2];
-#pragma unroll
-                for (int r = 0; r < kRegAmps; ++r) {
-                    const cplx ze = csel_conj({ z.x, z.y }, (unsigned)((r >> pa) ^ (r >> pb)) & 1u);
-                    const cplx v = cmul({ amp[r].x, amp[r].y }, ze);
-                    amp[r] = make_double2(v.x, v.y);
-                }
-            }
+            do_diag(amp, pp, cx, did);
         }
-        kind = nkind; oa = na; ob = nb; cs = ncs;
-        ++pc;
     }
 }
 
@@ -560,7 +600,7 @@ __global__ __launch_bounds__(BLOCK) void k_reg_eval(RegArgs a) {
 #pragma unroll
         for (int r = 0; r < kRegAmps; ++r) amp[r] = make_double2(0.0, 0.0);
         if (t == 0) amp[0].x = 1.0;
-        run_ops(amp, pp, cx, 0, nullptr);
+        run_phases(amp, pp, cx, 0, false, nullptr);
         measure(amp, a, cx, kt, krb, red, e, live, valid);
     }
 }
@@ -615,7 +655,7 @@ __global__ __launch_bounds__(BLOCK) void k_reg_psr(RegArgs a) {
 #pragma unroll
         for (int r = 0; r < kRegAmps; ++r) amp[r] = make_double2(0.0, 0.0);
         if (t == 0) amp[0].x = 1.0;
-        run_ops(amp, pp, cx, 0, ckpt);
+        run_phases(amp, pp, cx, 0, false, ckpt);
         measure(amp, a, cx, kt, krb, red, j * K, true, valid);
 
         for (int i = 0; i < P; ++i) {
@@ -674,7 +714,7 @@ __global__ __launch_bounds__(BLOCK) void k_reg_psr(RegArgs a) {
                     for (int r = 0; r < kRegAmps; ++r) amp[r] = make_double2(0.0, 0.0);
                     if (t == 0) amp[0].x = 1.0;
                 }
-                run_ops(amp, pp, cx, pc0, nullptr);
+                run_phases(amp, pp, cx, pc0, rdiag >= 0, nullptr);
                 measure(amp, a, cx, kt, krb, red, j * K + 1 + 2 * i + sgn, true, valid);
                 __syncthreads();
                 if (tid == 0 && kind == 0) {

@@ -397,8 +397,34 @@ bool reg_compile(int n, int n_theta, const std::vector<vqa_op>& gate_list, RegPr
         }
         P.ddesc.push_back(dd);
     }
-    for (size_t pc = 0; pc < P.ops.size(); ++pc)
-        if (P.ops[pc].kind == ROP_DIAG) P.ddesc[P.ops[pc].a].pc = (int)pc;
+    // ---- pack the op stream into phases ----
+    {
+        PhaseOp cur;
+        memset(&cur, 0, sizeof(cur));
+        int last_rank = -1;
+        auto flush = [&]() {
+            P.phases.push_back(cur);
+            memset(&cur, 0, sizeof(cur));
+            last_rank = -1;
+        };
+        for (const RegOp& op : P.ops) {
+            if (op.kind == ROP_END) break;
+            int rank, flag;
+            if (op.kind == ROP_XPOSE) { rank = 0; flag = PH_XPOSE; }
+            else if (op.kind == ROP_UREG) { rank = 1 + op.a; flag = PH_UREG0 << op.a; }
+            else if (op.kind == ROP_ULANE) { rank = 5 + op.a; flag = PH_ULANE0 << op.a; }
+            else { rank = 11; flag = PH_DIAG; }
+            if (rank <= last_rank) flush();
+            cur.flags |= flag;
+            last_rank = rank;
+            if (op.kind == ROP_XPOSE) cur.xdesc = op.a;
+            else if (op.kind == ROP_DIAG) { cur.ddesc = op.a; P.ddesc[op.a].pc = (int)P.phases.size(); }
+            else cur.ent[rank - 1] = op.b;
+        }
+        if (cur.flags) flush();
+        cur.flags = PH_END;
+        P.phases.push_back(cur);
+    }
 
     // ---- what each trainable parameter touches (parameter-shift sweeps) ----
     P.params.resize(n_theta);
@@ -466,6 +492,7 @@ bool reg_compile(int n, int n_theta, const std::vector<vqa_op>& gate_list, RegPr
     H.n_sign = (int)P.signs.size();
     H.n_params = n_theta;
     H.n_refs = (int)P.refs.size();
+    H.n_phases = (int)P.phases.size();
     H.has_xpose = P.n_xpose > 0;
 
     const size_t tab1 = ((size_t)H.n_uent + H.n_d1 + H.n_d2) * 16;
@@ -489,6 +516,7 @@ bool reg_compile(int n, int n_theta, const std::vector<vqa_op>& gate_list, RegPr
     H.off_signs = place(P.blob, P.signs);
     H.off_params = place(P.blob, P.params);
     H.off_refs = place(P.blob, P.refs);
+    H.off_phases = place(P.blob, P.phases);
     while (P.blob.size() % 16) P.blob.push_back(0);
     H.total_bytes = (int64_t)P.blob.size();
     memcpy(P.blob.data(), &H, sizeof(H));

@@ -43,6 +43,24 @@ struct RegOp {
     int32_t kind, a, b, c;
 };
 
+// The kernels run PHASES: one loop iteration executes, in this fixed order and
+// each only when its flag is set, a transposition, a rotation on each register
+// bit, a rotation on each lane bit and a diagonal stage.  Every block updates
+// the amplitudes in place behind a uniform branch, which is what lets the
+// register allocator keep the state in one set of registers across the loop.
+constexpr int32_t PH_XPOSE = 1 << 0;
+constexpr int32_t PH_UREG0 = 1 << 1;    // .. PH_UREG0 << 3
+constexpr int32_t PH_ULANE0 = 1 << 5;   // .. PH_ULANE0 << 5
+constexpr int32_t PH_DIAG = 1 << 11;
+constexpr int32_t PH_END = 1 << 12;
+struct PhaseOp {
+    int32_t flags;
+    int32_t xdesc;    // transposition descriptor (PH_XPOSE)
+    int32_t ddesc;    // D-stage descriptor (PH_DIAG)
+    int32_t ent[10];  // U-entry of register bits 0..3, lane bits 0..5 (0 when unused)
+    int32_t pad[3];
+};
+
 // an elementary 1-qubit gate inside a U-entry, or an angle term of a D-entry
 struct ElemGate {
     int32_t kind;  // VQA_GATE_*
@@ -85,7 +103,7 @@ struct DDesc {
     int32_t rt_begin, rt_count;       // a = register bit, b = thread bit number
     int32_t rr_begin, rr_count;       // a, b = register bits
     int32_t sign_id;                  // index of the stage's CZ / Z sign table, -1: no signs
-    int32_t pc;                       // index of the ROP_DIAG op that applies it
+    int32_t pc;                       // index of the phase that applies it
     int32_t pad[3];
 };
 
@@ -116,7 +134,7 @@ struct PatchRef {
 struct ParamInfo {
     int32_t ref_begin, ref_count;  // into refs[]
     int32_t resume_diag;           // first D-stage whose tables change; -1: restart from |0...0>
-    int32_t resume_pc;             // op index to resume at (0 when restarting)
+    int32_t resume_pc;             // phase to resume at, starting with its diagonal stage (0 when restarting)
 };
 
 struct RegHeader {
@@ -124,13 +142,14 @@ struct RegHeader {
     int32_t block;               // threads per workgroup
     int32_t S;                   // states per workgroup (explicit-list kernel)
     int32_t n_uent, n_d1, n_d2;  // per-evaluation table sizes (entries of 16 bytes)
-    int32_t n_elems, n_terms, n_ops, n_ddesc, n_xdesc, n_pairs, n_sign, n_params, n_refs;
+    int32_t n_elems, n_terms, n_ops, n_ddesc, n_xdesc, n_pairs, n_sign, n_params, n_refs, n_phases;
+    int32_t pad2;
     int32_t has_xpose;
     int32_t pad;
     int8_t final_qubit_at_pos[kMaxPos];
     // byte offsets of the arrays inside the device blob
     int64_t off_elems, off_uent, off_d1, off_d2, off_terms, off_ops, off_ddesc, off_xdesc, off_pairs,
-        off_signs, off_params, off_refs;
+        off_signs, off_params, off_refs, off_phases;
     int64_t total_bytes;
 };
 
@@ -142,7 +161,8 @@ struct RegProgram {
     std::vector<D1Entry> d1;
     std::vector<D2Entry> d2;
     std::vector<ElemGate> terms;
-    std::vector<RegOp> ops;
+    std::vector<RegOp> ops;        // host-side op stream the phases are packed from
+    std::vector<PhaseOp> phases;
     std::vector<DDesc> ddesc;
     std::vector<XDesc> xdesc;
     std::vector<PairRef> pairs;
