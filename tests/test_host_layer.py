@@ -1,0 +1,319 @@
+"""Host layer (QNN target objects + optimizers) on the CPU-oracle circuit:
+golden trajectories made with the reference's optimizers, estimator algebra
+against a scalar per-sample restatement, counters and mini-batch rules."""
+import itertools
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle_circuit import OracleCircuit
+from vqa_amd import optimizers
+from vqa_amd.qml_utils import create_ibm_HEA_ansatz
+from vqa_amd.qnn_base import myQNN_base, myQNN_regression
+from vqa_amd.qnn_classifier import myQNN_classifier
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "trajectories.json")
+
+
+def load_golden():
+    with open(GOLDEN) as f:
+        return json.load(f)
+
+
+def golden_qnn(d, circuit_cls):
+    ds = d["dataset"]
+    circuit = create_ibm_HEA_ansatz(ds["n_qubit"], ds["depth"], circuit_cls=circuit_cls)
+    return myQNN_base(ds["n_qubit"], circuit, np.array(ds["x_train"]), np.array(ds["y_train"]),
+                      np.array(ds["x_test"]), np.array(ds["y_test"]), min_approx_shots=0)
+
+
+def golden_hpara(case, n_params):
+    # the rules the generating script gave the reference's optimizers
+    return dict(LR_rule=lambda t, v=case["LR"]: v / (1 + 0.1 * t),
+                s_list_rule=lambda t, v=case["shots"]: np.full(n_params, v + 2.0 * t),
+                batch_size_rule=lambda t, v=case["batch"]: v + (t % 3),
+                LR_annealing_by_shots=False, s_list_annealing_by_shots=False, batch_size_annealing_by_shots=False)
+
+
+def run_golden_case(name, circuit_cls, tol):
+    d = load_golden()
+    case = d["cases"][name]
+    qnn = golden_qnn(d, circuit_cls)
+    np.random.seed(case["seed"])
+    qnn.compile(optimizer=name, hpara=golden_hpara(case, qnn.n_params), init_params=np.array(d["dataset"]["init"]))
+    res = qnn.fit(options=dict(max_iter=case["iters"], track_indicator="iteration_num"), auto_save=False)
+    assert len(res["para_evol"]) == case["iters"] + 1
+    assert np.max(np.abs(np.array(res["para_evol"]) - np.array(case["para_evol"]))) < tol
+    assert [int(v) for v in res["total_shots"]] == case["total_shots"]
+    assert [int(v) for v in res["total_call"]] == case["total_call"]
+    assert [int(v) for v in res["total_epoch"]] == case["total_epoch"]
+    assert np.allclose(res["total_time"], case["total_time"], rtol=0, atol=1e-9)
+    for got, want in zip(res["func_evol"], case["func_evol"]):
+        assert abs(got["test"] - want["test"]) < tol and abs(got["train"] - want["train"]) < tol
+
+
+@pytest.mark.parametrize("name", ["Adam", "SGD", "SGDM"])
+def test_golden_trajectory_oracle_circuit(name):
+    run_golden_case(name, OracleCircuit, 1e-12)
+
+
+# ---- estimator algebra ----------------------------------------------------------------------
+def scalar_power_estimator(E, n, min_approx, order, unbiased):
+    """Per-sample restatement of vqa/QNN/myQNNs_base.py:867-905 (CLT branch) + 820-865."""
+    est = E + np.random.randn() * np.sqrt((1.0 - E * E) / n)
+    M = est
+    if not unbiased:
+        EO = [M ** k for k in range(1, order + 1)]
+    else:
+        EO = [M]
+        if order >= 2:
+            EO.append((n / (n - 1.0)) * M ** 2 - 1 / (n - 1.0))
+        if order >= 3:
+            EO.append((n / (n - 1.0)) * (n / (n - 2.0)) * M ** 3 - (3.0 * n - 2) / (n - 1.0) / (n - 2.0) * M)
+        if order >= 4:
+            EO.append((n / (n - 1.0)) * (n / (n - 2.0)) * (n / (n - 3.0)) * M ** 4
+                      - ((n / (n - 1)) * ((6.0 * n - 8.0) / (n - 2.0)) * M ** 2 - 3.0 / (n - 1.0)) / (n - 3.0))
+    return EO, float(n) / (float(n) - 1.0) * (1.0 - est ** 2)
+
+
+def small_regressor(min_approx=0, n=4, depth=1, n_train=12, seed=3):
+    rng = np.random.default_rng(seed)
+    c = create_ibm_HEA_ansatz(n, depth, circuit_cls=OracleCircuit)
+    q = myQNN_regression(n, c, min_approx_shots=min_approx)
+    x = rng.uniform(0, 1, (n_train + 6, n))
+    tp = np.concatenate([rng.uniform(-3, 3, q.n_c_params), [1.4]])
+    y = q.generate_labels(x, tp)
+    q.set_data(x[:n_train], y[:n_train], x[n_train:], y[n_train:])
+    p0 = np.concatenate([rng.uniform(-3, 3, q.n_c_params), [0.9]])
+    return q, p0
+
+
+def test_unbiased_power_estimators_are_unbiased():
+    """Exhaustive enumeration over n = 6 shots of a +-1 variable: the estimators of
+    E^2, E^3, E^4 average exactly to the powers of the true mean."""
+    q, _ = small_regressor()
+    n, p_plus = 6, 0.3
+    E = 2 * p_plus - 1
+    acc = np.zeros(4)
+    for outcome in itertools.product([1, -1], repeat=n):
+        w = np.prod([p_plus if o == 1 else 1 - p_plus for o in outcome])
+        EO = q._unbiased_powerE_Pauli(np.mean(outcome), n, order=4, unbiased=True)
+        acc += w * np.array([float(v) for v in EO])
+    assert np.allclose(acc, [E, E ** 2, E ** 3, E ** 4], atol=1e-13)
+
+
+def test_grad_eval_matches_per_sample_restatement():
+    q, p0 = small_regressor()
+    shots = np.arange(q.n_params) * 3 + 40
+    B = 5
+    np.random.seed(11)
+    g = q.MSE_grad_eval(p0, shots, mini_batch_size=B)
+    counters = (q.shots_counter[0], q.call_counter[0], q.circuit_counter[0], q.epoch_counter[0])
+
+    # scalar loop in the reference's order, on the same exact expectation values
+    q2, _ = small_regressor()
+    np.random.seed(11)
+    idx = q2._pop_mini_batch_ind(B)
+    E = q2._psr_all(p0, idx)
+    y = q2.y_train[idx]
+    w = p0[-1]
+    base = [scalar_power_estimator(E[j, 0], shots[-1], 0, 4, True)[0] for j in range(B)]
+    EX0 = np.array([b[0] for b in base])
+    EX0sq = np.array([b[1] for b in base])
+    want = np.zeros_like(p0)
+    want[-1] = np.mean(2.0 * (-y * EX0 + w * EX0sq))
+    for i in range(q2.n_c_params):
+        Ep = np.array([scalar_power_estimator(E[j, 1 + 2 * i], shots[i], 0, 2, True)[0][0] for j in range(B)])
+        Em = np.array([scalar_power_estimator(E[j, 2 + 2 * i], shots[i], 0, 2, True)[0][0] for j in range(B)])
+        want[i] = np.mean((w * EX0 - y) * w * (Ep - Em))
+    assert np.max(np.abs(g - want)) < 1e-13
+    n_eval = B * (2 * q.n_c_params + 1)
+    assert counters == (B * (shots[-1] + 2 * shots[:-1].sum()), n_eval, n_eval, 1)
+
+
+def test_exact_mode_gradient_is_the_mse_gradient():
+    q, p0 = small_regressor(min_approx=-10)
+    N = len(q.x_train)
+    g = q.MSE_grad_eval(p0, np.full(q.n_params, 10), mini_batch_size=N)
+    assert q.shots_counter[0] == 0
+    h = 1e-6
+    for i in [0, 3, q.n_c_params - 1, q.n_params - 1]:
+        e = np.zeros_like(p0)
+        e[i] = h
+        fd = (q.exact_MSE(p0 + e, which="train") - q.exact_MSE(p0 - e, which="train")) / (2 * h)
+        assert abs(fd - g[i]) < 1e-7
+
+
+def test_loss_eval_and_ieval_exact_mode():
+    q, p0 = small_regressor(min_approx=-10)
+    N = len(q.x_train)
+    loss = q.MSE_loss_eval(p0, 50, mini_batch_size=N)
+    assert abs(loss - q.exact_MSE(p0, which="train")) < 1e-12
+    out = q.MSE_iEval(p0, np.full(q.n_params, 50), mini_batch_size=N)
+    g = q.MSE_grad_eval(p0, np.full(q.n_params, 50), mini_batch_size=N)
+    assert np.max(np.abs(out["grad"][:-1] - g[:-1])) < 0.2  # the debug branch samples the reported gradient
+    assert out["gvar_list_EV"].shape == p0.shape and np.all(np.isfinite(out["gvar_list_EV"]))
+    assert np.all(out["gvar_list_b"] >= 0)
+
+
+def test_ieval_clt_statistics():
+    q, p0 = small_regressor(min_approx=0)
+    N = len(q.x_train)
+    np.random.seed(5)
+    out = q.MSE_iEval(p0, np.full(q.n_params, 4000), mini_batch_size=N)
+    q.remain_ind = []
+    exact = myQNN_base.MSE_grad_eval(q, p0, np.full(q.n_params, 10), mini_batch_size=N, option_min_approx=-10)
+    # the shot-noise variance estimate must be consistent with the observed deviation
+    sigma = np.sqrt(out["gvar_list_EV"] / 4000 / N) + 1e-12
+    assert np.all(np.abs(out["grad"] - exact) < 6 * sigma + 1e-3)
+    assert set(out) == {"grad", "gvar_list_EV", "gvar_list_EVi", "gvar_list_EV0", "gvar_list_b", "grad_data_list"}
+    assert out["grad_data_list"].shape == (q.n_params, N)
+
+
+def test_ieval_irandom_statistics():
+    q, p0 = small_regressor(min_approx=0)
+    np.random.seed(9)
+    n = 60000
+    out = q.MSE_iEval_iRandom(p0, np.full(q.n_params, n))
+    q.remain_ind = []
+    exact = q.MSE_grad_eval(p0, np.full(q.n_params, 10), mini_batch_size=len(q.x_train), option_min_approx=-10)
+    sigma = np.sqrt(out["gvar_list"] / n)
+    assert np.all(np.abs(out["grad"] - exact) < 6 * sigma + 2e-3)
+
+
+def test_finite_shot_sampling_mode_counts_two_calls_per_state():
+    q, p0 = small_regressor(min_approx=-1)
+    np.random.seed(2)
+    B = 4
+    g = q.MSE_grad_eval(p0, np.full(q.n_params, 30), mini_batch_size=B)
+    n_eval = B * (2 * q.n_c_params + 1)
+    assert np.all(np.isfinite(g))
+    assert (q.call_counter[0], q.circuit_counter[0], q.shots_counter[0]) == (2 * n_eval, n_eval, 30 * n_eval)
+
+
+def test_mini_batch_epoch_wrap():
+    q, _ = small_regressor()
+    N = len(q.x_train)
+    np.random.seed(0)
+    seen = []
+    for _ in range(5):
+        seen.append(q._pop_mini_batch_ind(5))
+    assert all(len(s) == 5 for s in seen)
+    # N = 12: first epoch starts at the first call, the third call wraps into the second epoch
+    assert q.epoch_counter[0] == 3
+    first_epoch = np.concatenate([seen[0], seen[1], seen[2][:2]])
+    assert sorted(first_epoch.tolist()) == list(range(N))
+
+
+def test_builtin_optimizer_lookup_and_errors():
+    assert optimizers.get_optimizer_class("Adam") is optimizers.Adam
+    assert optimizers.get_optimizer_class(optimizers.SGD) is optimizers.SGD
+    y = optimizers.map_to_pi_range(np.array([4.0, -4.0, 1.0, 7.0]), [0, 1, 2])
+    assert np.allclose(y, [4.0 - 2 * np.pi, -4.0 + 2 * np.pi, 1.0, 7.0])
+
+
+def test_shot_indexed_rules_and_budget():
+    q, p0 = small_regressor(min_approx=0)
+    np.random.seed(4)
+    seen = []
+
+    def lr(s_tot):
+        seen.append(s_tot)
+        return 0.05
+
+    q.compile(optimizer="SGD", hpara=dict(LR_rule=lr, s_list_rule=np.full(q.n_params, 20), batch_size_rule=3), init_params=p0)
+    res = q.fit(options=dict(max_shots=20000), auto_save=False)
+    per_step = 3 * 20 * (2 * q.n_c_params + 1)
+    assert seen == [per_step * k for k in range(len(seen))]
+    assert res["total_shots"][-1] >= 20000 > res["total_shots"][-2]
+    assert q.model_params is res["para_evol"][-1]
+
+
+# ---- classifier --------------------------------------------------------------------------------
+def small_classifier(class_unbias=True, seed=5, n=4, n_train=10):
+    rng = np.random.default_rng(seed)
+    c = create_ibm_HEA_ansatz(n, 1, circuit_cls=OracleCircuit)
+    x = rng.uniform(0, 1, (n_train + 5, n))
+    y = rng.integers(0, 3, n_train + 5)
+    k = myQNN_classifier(n, c, x[:n_train], y[:n_train], x[n_train:], y[n_train:], class_unbias=class_unbias)
+    return k, rng.uniform(-3, 3, k.n_params)
+
+
+@pytest.mark.parametrize("unbias", [True, False])
+def test_classifier_exact_probabilities(unbias):
+    k, p = small_classifier(unbias)
+    probs = k.exact_prob_dist_data_by_data(k.x_train, p)
+    assert probs.shape == (len(k.x_train), 3)
+    assert np.allclose(probs.sum(axis=1), 1.0, atol=1e-12) and np.all(probs > -1e-12)
+    M = k._psr_marginals(p, np.arange(len(k.x_train)))
+    assert np.allclose(M.sum(axis=2), 1.0, atol=1e-12)
+    assert np.max(np.abs(k._prob_from_marginal(M[:, 0]) - probs)) < 1e-12
+    pred = k.exact_predict(k.x_train, p)
+    assert np.array_equal(pred, np.argmax(probs, axis=1))
+    d = k.exact_predict_error_and_MSE(p)
+    assert set(d) == {"test", "train", "test loss", "train loss"}
+    assert abs(d["train loss"] - np.sum((probs - k.y_train_1hot) ** 2) / len(probs)) < 1e-12
+
+
+@pytest.mark.parametrize("partial", [True, False])
+def test_classifier_mse_gradient_converges_to_exact(partial):
+    k, p = small_classifier()
+    N = len(k.x_train)
+    np.random.seed(21)
+    n = 200000
+    g = k.MSE_grad_eval(p, np.full(k.n_params, n), mini_batch_size=N, partial_MSE=partial)
+    n_eval = N * (2 * k.n_params + 1)
+    assert (k.shots_counter[0], k.call_counter[0], k.circuit_counter[0]) == (n * n_eval, n_eval, n_eval)
+    M = k._psr_marginals(p, np.arange(N))
+    P = k._prob_from_marginal(M)  # [N, 2P+1, 3]
+    # batches are drawn in permuted order; means over the full set do not depend on it
+    yi = np.asarray(k.y_train, int)
+    want = np.zeros_like(p)
+    for i in range(k.n_params):
+        dp = P[:, 1 + 2 * i] - P[:, 2 + 2 * i]
+        if partial:
+            want[i] = np.mean((P[np.arange(N), 0, yi] - 1.0) * dp[np.arange(N), yi])
+        else:
+            want[i] = np.mean(np.sum((P[:, 0] - k.y_train_1hot) * dp, axis=1))
+    assert np.max(np.abs(g - want)) < 5e-3
+
+
+def test_classifier_ieval_and_ce():
+    k, p = small_classifier()
+    np.random.seed(8)
+    out = k.MSE_iEval(p, np.full(k.n_params, 500), mini_batch_size=6, partial_MSE=True)
+    assert np.all(out["gvar_list_EV"] >= 0) and out["grad_data_list"].shape == (k.n_params, 6)
+    out = k.MSE_iEval(p, np.full(k.n_params, 500), mini_batch_size=6, partial_MSE=False)
+    assert np.all(np.isfinite(out["gvar_list_EV"]))
+    out = k.MSE_iEval_iRandom(p, np.full(k.n_params, 3000))
+    assert np.all(out["gvar_list"] > 0)
+    g = k.CE_grad_eval(p, np.full(k.n_params, 400), mini_batch_size=6, L2_reg_lmd=0.0)
+    out = k.CE_iEval(p, np.full(k.n_params, 400), mini_batch_size=6)
+    assert np.all(np.isfinite(g)) and np.all(np.isfinite(out["gvar_list_EV"]))
+    with pytest.raises(NotImplementedError):
+        k.MSE_grad_eval(p, np.full(k.n_params, 10), mini_batch_size=2, use_QEM=True)
+
+
+def test_classifier_fit_with_cross_entropy():
+    k, p = small_classifier()
+    np.random.seed(3)
+    k.compile(optimizer="Adam", loss="cross_entropy",
+              hpara=dict(LR_rule=0.05, s_list_rule=np.full(k.n_params, 50), batch_size_rule=4), init_params=p)
+    res = k.fit(options=dict(max_iter=3), auto_save=False)
+    assert len(res["para_evol"]) == 4 and set(res["func_evol"][-1]) == {"test", "train"}
+
+
+def test_save_to_file_roundtrip(tmp_path):
+    import pickle
+
+    q, p0 = small_regressor()
+    q.compile(optimizer="SGD", hpara=dict(LR_rule=0.01, s_list_rule=np.full(q.n_params, 10), batch_size_rule=2), init_params=p0)
+    res = q.fit(options=dict(max_iter=2), auto_save=True, save_directory=str(tmp_path))
+    files = list(tmp_path.iterdir())
+    assert len(files) == 1
+    with open(files[0], "rb") as f:
+        data = pickle.load(f)
+    assert np.allclose(data["results"]["para_evol"][-1], res["para_evol"][-1])
+    assert data["object"].n_params == q.n_params

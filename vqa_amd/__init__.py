@@ -10,5 +10,8 @@ from .qml_utils import (  # noqa: F401
     create_ry_rz_cz_ansatz,
     create_ry_cz_ansatz,
 )
+from .qnn_base import myQNN_base, myQNN_regression  # noqa: F401
+from .qnn_classifier import myQNN_classifier  # noqa: F401
+from . import optimizers  # noqa: F401
 
 __version__ = "0.1.0"

@@ -1,0 +1,665 @@
+"""QNN regressor target object on the batched HIP engine.
+
+Drop-in counterpart of ``myQNN_base`` (vqa/QNN/myQNNs_base.py:264-1675): same
+constructor, same optimizer-facing protocol (``methods_for_optimization``,
+``n_params`` / ``n_c_params``, one-element-list counters, overhead times) and
+the same estimator algebra.  What changes is how circuits are evaluated: where
+the reference loops ``circuit.run(x)`` over samples, shifts and parameters
+(myQNNs_base.py:1110-1124, 1381-1394), this class asks the circuit object for
+one batched sweep (``psr_full`` / ``eval_batch`` of vqa_amd.LearningCircuit)
+and applies the reference's per-sample statistics to the returned matrix of
+exact expectation values with NumPy:
+
+* exact mode (``min_approx_shots == -10``), CLT mode (``n >= min_approx_shots``:
+  ``E + randn() * sqrt((1 - E^2) / n)``) and finite-shot mode (binomial draws on
+  the exact Z0 distribution; the reference draws basis states with qulacs'
+  private generator, so this mode agrees in distribution only);
+* the NumPy global generator is consumed in the reference's order: unshifted
+  evaluation first (sample-major), then per parameter the +shift samples and
+  the -shift samples;
+* ``shots_counter`` / ``call_counter`` / ``circuit_counter`` / ``epoch_counter``
+  advance by the same totals as the per-sample code.
+"""
+from __future__ import annotations
+
+import copy
+import os
+import pickle
+import uuid
+from typing import Optional
+
+import numpy as np
+
+from .observable import Observable, z_observable
+from . import optimizers as _optimizers
+
+
+def _np(a):
+    """numpy view of a result that may be a torch tensor on the GPU."""
+    if a is None:
+        return None
+    if hasattr(a, "detach"):
+        return a.detach().cpu().numpy()
+    return np.asarray(a)
+
+
+def split_array_equally(arr):
+    """vqa/QNN/myQNNs_base.py:234-245."""
+    mid = len(arr) // 2
+    return arr[:mid], arr[mid:2 * mid]
+
+
+class myQNN_base:
+    """Regressor: prediction = params[-1] * <Z_0>; the last parameter is a
+    trainable scale.  See the module docstring for what is and is not the
+    reference's code path."""
+
+    def __init__(self, n_qubits, learning_circuit, x_train=None, y_train=None, x_test=None, y_test=None,
+                 min_approx_shots=-1, setting_dict=None, id_string="QNN", file_id=None, obs=None,
+                 shot_time=1.0, per_circuit_overhead=0.0, communication_overhead=0.0,
+                 max_sub_nqubits_sampling_aft_partial_tr=6):
+        self.circuit = learning_circuit
+        self.n_c_params = len(self.circuit.get_parameters())
+        self.n_params = self.n_c_params + 1  # + the re-normalisation coefficient
+        self.n_qubits = n_qubits
+        self._handles = {}
+        self.set_data(x_train, y_train, x_test, y_test)
+        self.methods_for_optimization = {}
+        if setting_dict:
+            self.set_methods_for_optimizer(setting_dict)
+        self.min_approx_shots = min_approx_shots
+        self.call_counter = [0]
+        self.shots_counter = [0]
+        self.circuit_counter = [0]
+        self.epoch_counter = [0]
+        self.communication_overhead = communication_overhead
+        self.shot_time = shot_time
+        self.per_circuit_overhead = per_circuit_overhead
+        self.id_string = id_string
+        self.results_dict = {}
+        self.file_id = file_id if file_id else str(uuid.uuid4())
+        self.exact_cost_evol = []
+        self.remain_ind = []
+        self._dim = 2 ** self.n_qubits
+        if obs is None:
+            obs = self._default_obs()
+        # as in the reference, a user observable is only serialised; the model always reads Z_0
+        self.obs_json = obs.to_json()
+        self.target_indices_list = [obs.get_term(i).get_index_list() for i in range(obs.get_term_count())]
+        self.max_sub_nqubits_sampling_aft_partial_tr = max_sub_nqubits_sampling_aft_partial_tr
+        self.n_shots_test = 1e2
+
+    # ---- bookkeeping identical to the reference ---------------------------------
+    def get_parameter_count(self, return_circuit_parameter_count=False):
+        return self.n_c_params if return_circuit_parameter_count else self.n_params
+
+    def set_data(self, x_train, y_train, x_test, y_test):
+        if x_train is not None and y_train is not None:
+            self.x_train = np.array(x_train)
+            self.y_train = np.array(y_train)
+            self.num_train_data = len(x_train)
+            self._uniform_wt = np.full(len(self.x_train), 1.0)
+            self._uniform_wt_dist = np.full(len(self.x_train), 1.0) / len(self.x_train)
+            self._handles.pop("train", None)
+        if x_test is not None and y_test is not None:
+            self.x_test = np.array(x_test)
+            self.y_test = np.array(y_test)
+            self._handles.pop("test", None)
+
+    def _default_obs(self):
+        return z_observable(self.n_qubits, 0)
+
+    def remove_data(self):
+        for a in ("x_train", "y_train", "num_train_data", "x_test", "y_test"):
+            if hasattr(self, a):
+                delattr(self, a)
+        self._handles = {}
+
+    def get_data(self):
+        return (getattr(self, "x_train", []), getattr(self, "y_train", []),
+                getattr(self, "x_test", []), getattr(self, "y_test", []))
+
+    def set_overhead_time(self, shot_time=None, per_circuit_overhead=None, communication_overhead=None):
+        if shot_time is not None:
+            self.shot_time = shot_time
+        if per_circuit_overhead is not None:
+            self.per_circuit_overhead = per_circuit_overhead
+        if communication_overhead is not None:
+            self.communication_overhead = communication_overhead
+
+    def set_methods_for_optimizer(self, setting_dict):
+        for key, method_name in setting_dict.items():
+            self.methods_for_optimization[key] = getattr(self, method_name)
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d["_handles"] = {}  # device-resident input matrices are rebuilt on demand
+        d["_z0"] = None     # holds a native handle
+        d["methods_for_optimization"] = {k: v.__name__ for k, v in self.methods_for_optimization.items()}
+        return d
+
+    def __setstate__(self, d):
+        names = d.pop("methods_for_optimization", {})
+        self.__dict__.update(d)
+        self.methods_for_optimization = {k: getattr(self, v) for k, v in names.items()}
+
+    # ---- compile / fit (myQNNs_base.py:540-690) ------------------------------------
+    _LOSS_METHODS = {
+        "mean_squared_error": {
+            "func_to_track": "MSE_both_exact_loss_to_track", "loss": "MSE_loss_eval", "grad": "MSE_grad_eval",
+            "iEvaluate": "MSE_iEval", "iEvaluate_iRandom": "MSE_iEval_iRandom",
+        },
+    }
+
+    def compile(self, optimizer="SGD", loss="mean_squared_error", hpara=None, init_params=None, min_approx_shots=None,
+                x_train=None, y_train=None, x_test=None, y_test=None, shot_time=None, per_circuit_overhead=None,
+                communication_overhead=None, init_spec_dict=None, manual_methods_setting_dict=None):
+        self.set_data(x_train, y_train, x_test, y_test)
+        self._optimizer_name = optimizer if isinstance(optimizer, str) else optimizer.__name__
+        if min_approx_shots is not None:
+            self.min_approx_shots = min_approx_shots
+        optimizer_class = _optimizers.get_optimizer_class(optimizer)
+        if init_spec_dict is None:
+            init_spec_dict = {}
+        if init_params is not None:
+            init_spec_dict["init_params"] = init_params
+            self.model_params = init_params
+        self.set_overhead_time(shot_time, per_circuit_overhead, communication_overhead)
+        if manual_methods_setting_dict is not None:
+            self.set_methods_for_optimizer(manual_methods_setting_dict)
+        elif loss in self._LOSS_METHODS:
+            self.set_methods_for_optimizer(self._LOSS_METHODS[loss])
+        else:
+            raise ValueError(f"loss {loss!r} is not available for {type(self).__name__}")
+        init_spec_dict["target_obj"] = self
+        self.optimizer = optimizer_class(hpara=hpara, init_spec_dict=init_spec_dict)
+        self._optimized = False
+
+    def fit(self, init_params=None, options=None, hpara=None, init_spec_dict=None, Return_results=True,
+            store_results_in_self=False, auto_save=True, save_self_obj=True, save_directory="single_optimization",
+            process_id=0, **kwargs):
+        if not hasattr(self, "optimizer"):
+            print("Optimizer has not been specified")
+            return
+        if options is None:
+            options = {}
+        options["process_id"] = process_id
+        if not self._optimized:
+            if init_spec_dict is None:
+                init_spec_dict = {}
+            if init_params is not None:
+                init_spec_dict["init_params"] = init_params
+                self.model_params = init_params
+            init_spec_dict["target_obj"] = self
+            results = self.optimizer.new_optimize(init_spec_dict=init_spec_dict, hpara=hpara, options=options, **kwargs)
+        else:
+            results = self.optimizer.continue_optimize(options_to_update=options, kwargs_to_update=kwargs)
+        self.model_params = results["para_evol"][-1]
+        if store_results_in_self:
+            self.results_dict.setdefault(self._optimizer_name, []).append(results)
+        self.elapsed_time_for_optimization = getattr(self.optimizer, "elapsed_time", None)
+        self._optimized = True
+        if auto_save:
+            self.save_to_file(results=results, save_self_obj=save_self_obj, directory=save_directory)
+        return results
+
+    def save_to_file(self, results=None, save_self_obj=True, directory=None):
+        """myQNNs_base.py:404-451 with pickle; device handles are dropped by __getstate__."""
+        name = f"{self.id_string}_model_{getattr(self, '_optimizer_name', 'none')}_{self.file_id}.pkl"
+        if directory:
+            os.makedirs(directory, exist_ok=True)
+            name = os.path.join(directory, name)
+        data = {"results": results}
+        if save_self_obj:
+            try:
+                shadow = copy.copy(self)
+                shadow.__dict__.pop("optimizer", None)
+                shadow.circuit = None  # input_func lambdas do not pickle; the circuit is rebuilt by its builder
+                pickle.dumps(shadow)
+                data["object"] = shadow
+            except Exception as e:  # same policy as the reference: fall back to the results
+                print(f"An error occurred while saving self object: {e}")
+        with open(name, "wb") as f:
+            pickle.dump(data, f)
+        return name
+
+    # ---- batched circuit evaluation ------------------------------------------------
+    def _obs_list(self):
+        if getattr(self, "_z0", None) is None:
+            self._z0 = self._default_obs()
+        return [self._z0]
+
+    def _handle(self, which):
+        """Input-angle matrix of the train / test set, resident where the circuit wants it."""
+        if which not in self._handles:
+            x = self.x_train if which == "train" else self.x_test
+            self._handles[which] = self.circuit.upload_inputs(x)
+        return self._handles[which]
+
+    def _expect_all(self, params, x_list=None, which=None, idx=None):
+        """Exact <Z0> for each sample: an explicit x_list, or rows idx of a resident set."""
+        theta = np.asarray(params[:self.n_c_params], dtype=np.float64)
+        if x_list is not None:
+            inputs = self.circuit.upload_inputs(np.asarray(x_list))
+            e, _ = self.circuit.eval_batch(theta, inputs, obs_list=self._obs_list())
+        else:
+            e, _ = self.circuit.eval_batch(theta, self._handle(which), sample_idx=None if idx is None else np.asarray(idx, np.int32),
+                                           obs_list=self._obs_list())
+        return _np(e)[:, 0]
+
+    def _psr_all(self, params, idx):
+        """Exact <Z0> of the 2P+1 parameter-shift instances of each selected training sample: [B, 2P+1]."""
+        theta = np.asarray(params[:self.n_c_params], dtype=np.float64)
+        e, _ = self.circuit.psr_full(theta, self._handle("train"), sel=np.asarray(idx, np.int32), obs_list=self._obs_list())
+        return _np(e)[:, :, 0]
+
+    # ---- per-sample statistics (myQNNs_base.py:715-738, 799-905) ----------------------
+    def _unbiased_powerE_Pauli(self, sample_mean, n_samples, order=4, unbiased=False):
+        """myQNNs_base.py:820-865, elementwise over samples."""
+        n = np.asarray(n_samples, dtype=float)
+        M = np.asarray(sample_mean, dtype=float)
+        out = [M]
+        if order >= 2:
+            out.append((n / (n - 1.0)) * M ** 2 - 1 / (n - 1.0) if unbiased else M ** 2)
+        if order >= 3:
+            out.append((n / (n - 1.0)) * (n / (n - 2.0)) * M ** 3 - (3.0 * n - 2) / (n - 1.0) / (n - 2.0) * M
+                       if unbiased else M ** 3)
+        if order >= 4:
+            out.append((n / (n - 1.0)) * (n / (n - 2.0)) * (n / (n - 3.0)) * M ** 4
+                       - ((n / (n - 1)) * ((6.0 * n - 8.0) / (n - 2.0)) * M ** 2 - 3.0 / (n - 1.0)) / (n - 3.0)
+                       if unbiased else M ** 4)
+        return out[:max(order, 1)]
+
+    def _draw_means(self, exact, n_s, min_approx):
+        """Estimated <Z0> of each sample from its exact value: CLT noise or binomial
+        sampling per sample, global NumPy generator, sample order."""
+        exact = np.asarray(exact, dtype=float)
+        n_s = np.asarray(n_s)
+        B = len(exact)
+        sampled = (n_s < min_approx) | (min_approx < 0)
+        self.call_counter[0] += B + int(sampled.sum())
+        self.shots_counter[0] += int(n_s.sum())
+        var = 1.0 - exact ** 2
+        with np.errstate(divide="ignore", invalid="ignore"):
+            if not sampled.any():
+                return exact + np.random.randn(B) * np.sqrt(var / n_s)
+            est = np.empty(B)
+            p_minus = np.clip(0.5 * (1.0 - exact), 0.0, 1.0)
+            if sampled.all():
+                k = np.random.binomial(n_s.astype(np.int64), p_minus)
+                return (n_s - 2.0 * k) / n_s
+            for j in range(B):  # mixed modes: keep the generator in sample order
+                if sampled[j]:
+                    est[j] = (n_s[j] - 2.0 * np.random.binomial(int(n_s[j]), p_minus[j])) / n_s[j]
+                else:
+                    est[j] = exact[j] + np.random.randn() * np.sqrt(var[j] / n_s[j])
+            return est
+
+    def _estimate(self, exact, n_s, min_approx, order=4, Return_var=False, unbiased=False, no_power=False):
+        """Batched _single_state_hybrid_sampler[_power] (myQNNs_base.py:799-818, 867-905)."""
+        exact = np.asarray(exact, dtype=float)
+        n_s = np.asarray(n_s)
+        self.circuit_counter[0] += len(exact)
+        if min_approx == -10 and not no_power:
+            self.call_counter[0] += len(exact)
+            EO = [exact ** k for k in range(1, order + 1)]
+            return (EO, 1.0 - exact ** 2) if Return_var else EO
+        M = self._draw_means(exact, n_s, min_approx)
+        nf = n_s.astype(float)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            var = nf / (nf - 1.0) * (1.0 - M ** 2)
+            if no_power:
+                return (M, var) if Return_var else M
+            EO = self._unbiased_powerE_Pauli(M, nf, order=order, unbiased=unbiased)
+        return (EO, var) if Return_var else EO
+
+    # the reference's per-call names, batched ------------------------------------------
+    def _sample_obs_data_by_data(self, params, x_eval, n_s_list, min_approx, order=4, Return_var=False, unbiased=False):
+        """myQNNs_base.py:1100-1125 for an explicit list of samples."""
+        exact = self._expect_all(params, x_list=x_eval)
+        return self._estimate(exact, n_s_list, min_approx, order=order, Return_var=Return_var, unbiased=unbiased)
+
+    def _sample_predict_scaled(self, x_eval, n_s_list, params=None, min_approx=None, Return_var=False):
+        """myQNNs_base.py:1044-1070."""
+        if min_approx is None:
+            min_approx = self.min_approx_shots
+        if params is None:
+            params = self.model_params
+        exact = self._expect_all(params, x_list=x_eval)
+        w = params[-1]
+        if Return_var:
+            M, var = self._estimate(exact, n_s_list, min_approx, Return_var=True, no_power=True)
+            return w * M, var * w ** 2
+        return self._estimate(exact, n_s_list, min_approx, no_power=True) * w
+
+    def _sample_predict_no_scale(self, x_eval, n_s_list, params=None, min_approx=None, Return_var=False):
+        """myQNNs_base.py:1072-1097."""
+        if min_approx is None:
+            min_approx = self.min_approx_shots
+        if params is None:
+            params = self.model_params
+        exact = self._expect_all(params, x_list=x_eval)
+        return self._estimate(exact, n_s_list, min_approx, Return_var=Return_var, no_power=True)
+
+    def sample_predict(self, x_eval, n_s_list, params=None, min_approx=None, Return_var=False):
+        return self._sample_predict_scaled(x_eval, n_s_list, params, min_approx, Return_var)
+
+    # ---- exact forward (myQNNs_base.py:907-994) -----------------------------------------
+    def exact_predict(self, x_list, params=None):
+        if params is None:
+            params = self.model_params
+        return params[-1] * self._expect_all(params, x_list=x_list)
+
+    def _exact_predict_set(self, which, params):
+        return params[-1] * self._expect_all(params, which=which)
+
+    def exact_MSE(self, params, which="test", ret_both=False, log_evol=False):
+        if ret_both:
+            which = "test"
+        if which == "train":
+            y_pred = self._exact_predict_set("train", params).astype(float)
+            MSE = np.sum(np.square(y_pred - self.y_train)) / len(self.y_train)
+            if log_evol:
+                self.exact_cost_evol.append(self.exact_MSE(params, which="test"))
+            return MSE
+        y_pred = self._exact_predict_set("test", params).astype(float)
+        MSE = np.sum(np.square(y_pred - self.y_test)) / len(self.y_test)
+        if log_evol:
+            self.exact_cost_evol.append(MSE)
+        if ret_both:
+            return {"test": MSE, "train": self.exact_MSE(params, which="train", ret_both=False)}
+        return MSE
+
+    def exact_BMA_predict(self, x_list, params_list, num_avg):
+        num_avg = min(len(params_list), num_avg)
+        return np.mean(np.array([self.exact_predict(x_list, p) for p in params_list[-num_avg:]]), axis=0)
+
+    def exact_BMA_MSE(self, params_list, num_avg, which="test", ret_both=False):
+        if ret_both:
+            which = "test"
+        if which == "train":
+            y_pred = self.exact_BMA_predict(self.x_train, params_list, num_avg).astype(float)
+            return np.sum(np.square(y_pred - self.y_train)) / len(self.y_train)
+        y_pred = self.exact_BMA_predict(self.x_test, params_list, num_avg).astype(float)
+        MSE = np.sum(np.square(y_pred - self.y_test)) / len(self.y_test)
+        if ret_both:
+            return {"test": MSE, "train": self.exact_BMA_MSE(params_list, num_avg, which="train")}
+        return MSE
+
+    def MSE_exact_train_loss(self, params):
+        return self.exact_MSE(params, which="train", log_evol=True)
+
+    def MSE_both_exact_loss_to_track(self, params):
+        return self.exact_MSE(params, which="test", ret_both=True, log_evol=False)
+
+    def reset_exact_cost_evol(self):
+        self.exact_cost_evol = []
+
+    def generate_labels(self, x_data, target_params):
+        return self.exact_predict(x_data, target_params)
+
+    # ---- variance estimators (myQNNs_base.py:1205-1316, 1599-1617) -----------------------
+    def _estimate_MSEgrad_mean_condVar(self, y_eval, E0pow_data_list, w=1.0, second_order=True, n0=None,
+                                       Scale_para=True, Eppow_data_list=None, Empow_data_list=None,
+                                       var_0=None, var_p=None, var_m=None):
+        EX = np.array(E0pow_data_list[0])
+        EX_2 = np.array(E0pow_data_list[1])
+        if Scale_para:
+            EX_3 = np.array(E0pow_data_list[2])
+            EX_4 = np.array(E0pow_data_list[3])
+            a = -2 * y_eval
+            b = 2 * w
+            est = a ** 2 + 4.0 * a * b * EX + (4.0 * b ** 2 - a ** 2) * EX_2 - 4 * a * b * EX_3 - 4 * b ** 2 * EX_4
+            if second_order and n0:
+                est += 2 * b ** 2 * (1 - 2 * EX + EX_2) / (n0 - 1)
+            mean_condVar = np.mean(est)
+            if mean_condVar < 0:
+                Var_X = var_0
+                est = np.square(a + 2 * b * EX) * Var_X
+                if second_order and n0:
+                    est += 2 * b ** 2 * np.square(Var_X) / (n0 - 1)
+                mean_condVar = np.mean(est)
+            return mean_condVar
+        EXp = np.array(Eppow_data_list[0])
+        EXm = np.array(Empow_data_list[0])
+        EXp_2 = np.array(Eppow_data_list[1])
+        EXm_2 = np.array(Empow_data_list[1])
+        w2 = w ** 2
+        y2 = np.square(y_eval)
+        yw = w * y_eval
+        err2 = y2 - 2.0 * yw * EX + w2 * EX_2
+        dpdt2 = w2 * (EXp_2 - 2.0 * EXp * EXm + EXm_2)
+        var_dpdt = w2 * (var_p + var_m)
+        var_err = w2 * var_0
+        est_i = err2 * var_dpdt
+        est_0 = var_err * dpdt2
+        if second_order and n0:
+            est_i = est_i + var_err * var_dpdt / n0
+        EV_i = np.mean(est_i)
+        EV_0 = np.mean(est_0)
+        mean_condVar = EV_i + EV_0
+        if EV_0 < 0:
+            dpdt2 = w2 * np.square(EXp - EXm)
+            EV_0 = np.mean(var_err * dpdt2)
+        if EV_i < 0:
+            err2 = np.square(y_eval - w * EX)
+            est_i = err2 * var_dpdt
+            if second_order and n0:
+                est_i = est_i + var_err * var_dpdt / n0
+            EV_i = np.mean(est_i)
+        if mean_condVar < 0:
+            mean_condVar = EV_i + EV_0
+        return mean_condVar, EV_i, EV_0
+
+    def _estimate_MSEgrad_Var_condMean(self, y_eval, grad_data_list, size, E0pow_data_list, w=1.0, Scale_para=True,
+                                       Eppow_data_list=None, Empow_data_list=None):
+        EX_2 = np.array(E0pow_data_list[1])
+        if Scale_para:
+            EX_3 = np.array(E0pow_data_list[2])
+            EX_4 = np.array(E0pow_data_list[3])
+            a = -2 * y_eval
+            b = 2 * w
+            grad_data2_list = a ** 2 * EX_2 + 2.0 * a * b * EX_3 + b ** 2 * EX_4
+        else:
+            EX = np.array(E0pow_data_list[0])
+            EXp = np.array(Eppow_data_list[0])
+            EXm = np.array(Empow_data_list[0])
+            EXp_2 = np.array(Eppow_data_list[1])
+            EXm_2 = np.array(Empow_data_list[1])
+            grad_data2_list = (y_eval ** 2 - 2.0 * y_eval * w * EX + w ** 2 * EX_2) * w ** 2 * (EXp_2 + EXm_2 - 2 * EXp * EXm)
+        est = np.sum(grad_data2_list) / size - (np.sum(grad_data_list) ** 2 - np.sum(np.square(grad_data_list))) / (size * (size - 1.0))
+        if est < 0:
+            est = np.var(grad_data_list, ddof=1)
+        return est
+
+    def _direct_sample_MSEgrad_varUB_whole(self, y_eval, outcomes_whole_no_shift, w=1, Scale_para=False,
+                                           outcomes_whole_p=None, outcomes_whole_m=None):
+        if Scale_para:
+            out1_list, out2_list = zip(*[split_array_equally(o) for o in outcomes_whole_no_shift])
+            out1_array = np.concatenate(out1_list)
+            out2_array = np.concatenate(out2_list)
+            repeat_counts = [len(o) for o in out1_list]
+            grad_outcomes_data = 2 * (w * out1_array - np.repeat(y_eval, repeat_counts)) * out2_array
+        else:
+            outcomes_0 = np.concatenate(outcomes_whole_no_shift)
+            outcomes_p = np.concatenate(outcomes_whole_p)
+            outcomes_m = np.concatenate(outcomes_whole_m)
+            repeat_counts = [len(o) for o in outcomes_whole_no_shift]
+            grad_outcomes_data = (w * outcomes_0 - np.repeat(y_eval, repeat_counts)) * w * (outcomes_p - outcomes_m)
+        return np.var(grad_outcomes_data, ddof=1)
+
+    # ---- mini-batches (myQNNs_base.py:1318-1344) ----------------------------------------
+    def reset_remain_ind(self):
+        self.remain_ind = (np.random.permutation(len(self.x_train))).astype(int)
+
+    def _pop_mini_batch_ind(self, mini_batch_size):
+        if len(self.remain_ind) < mini_batch_size:
+            eval_ind = np.array(self.remain_ind).copy()
+            mini_batch_size -= len(eval_ind)
+            self.reset_remain_ind()
+            self.epoch_counter[0] += 1
+            eval_ind = np.concatenate((eval_ind, self.remain_ind[:mini_batch_size])).astype(int)
+            self.remain_ind = self.remain_ind[mini_batch_size:]
+        else:
+            eval_ind = self.remain_ind[:mini_batch_size]
+            self.remain_ind = self.remain_ind[mini_batch_size:]
+        return eval_ind
+
+    def _batch_setup(self, mini_batch_size, option_min_approx, option_weight):
+        min_approx = self.min_approx_shots if option_min_approx is None else option_min_approx
+        wt_dist = self._uniform_wt.copy() if option_weight is None else np.array(option_weight).copy()
+        eval_ind = self._pop_mini_batch_ind(mini_batch_size)
+        return min_approx, np.array(wt_dist)[eval_ind], eval_ind, self.y_train[eval_ind]
+
+    # ---- parameter-shift oracles -----------------------------------------------------------
+    def MSE_grad_eval(self, params, n_shots_list, mini_batch_size=None, option_min_approx=None, option_weight=None):
+        """myQNNs_base.py:1346-1395: grad[i] = mean((w E0 - y) w (E+ - E-)), grad[-1] = mean(2(-y E0 + w E0^2_ub))."""
+        grad = np.zeros_like(params)
+        min_approx, wt_dist, eval_ind, y_eval = self._batch_setup(mini_batch_size, option_min_approx, option_weight)
+        E = self._psr_all(params, eval_ind)
+        n_shots_data_list = np.floor(n_shots_list[-1] * wt_dist).astype(int)
+        w = params[-1]
+        EX0 = self._estimate(E[:, 0], n_shots_data_list, min_approx, order=4, unbiased=True)
+        EX0_list = EX0[0]
+        self.cache_train_pred = w * EX0_list
+        self.cache_y_train_eval = y_eval
+        grad[-1] = np.mean(2.0 * (-y_eval * EX0_list + w * EX0[1]))
+        for i in range(len(params) - 1):
+            n_shots_data_list = np.floor(n_shots_list[i] * wt_dist).astype(int)
+            EXp = self._estimate(E[:, 1 + 2 * i], n_shots_data_list, min_approx, order=2, unbiased=True)
+            EXm = self._estimate(E[:, 2 + 2 * i], n_shots_data_list, min_approx, order=2, unbiased=True)
+            grad[i] = np.mean((w * EX0_list - y_eval) * w * (EXp[0] - EXm[0]))
+        return grad
+
+    def MSE_loss_eval(self, params, n_shots, mini_batch_size=None, option_min_approx=None, option_weight=None):
+        """myQNNs_base.py:1397-1419."""
+        min_approx, wt_dist, eval_ind, y_eval = self._batch_setup(mini_batch_size, option_min_approx, option_weight)
+        n_shots_data_list = np.floor(n_shots * wt_dist).astype(int)
+        exact = self._expect_all(params, which="train", idx=eval_ind)
+        EX0 = self._estimate(exact, n_shots_data_list, min_approx, order=2, unbiased=True)
+        w = params[-1]
+        return np.mean(w ** 2 * EX0[1] - 2.0 * w * y_eval * EX0[0] + np.square(y_eval))
+
+    def MSE_iEval(self, params, n_shots_list, option_min_approx=None, option_weight=None, mini_batch_size=None,
+                  Max_n_shots0=True, second_order=True):
+        """myQNNs_base.py:1421-1596: gradient plus the variance estimates the shot-adaptive optimizers consume."""
+        grad = np.zeros_like(params)
+        gvar_list_b = np.zeros_like(params)
+        gvar_list_EV = np.zeros_like(params)
+        gvar_list_EVi = np.zeros_like(params)
+        gvar_list_EV0 = np.zeros_like(params)
+        min_approx, wt_dist, eval_ind, y_eval = self._batch_setup(mini_batch_size, option_min_approx, option_weight)
+        size = mini_batch_size
+        grad_data_list = np.zeros((len(params), len(eval_ind)))
+        E = self._psr_all(params, eval_ind)
+        n0 = n_shots_list[-1]
+        n_shots0 = np.max(n_shots_list) if Max_n_shots0 else n_shots_list[-1]
+        n_shots_data_list = np.floor(n_shots0 * wt_dist).astype(int)
+        w = params[-1]
+        debug = min_approx == -10
+        if debug:
+            EX0pow_exact, var_0_exact = self._estimate(E[:, 0], n_shots_data_list, -10, order=4, Return_var=True, unbiased=True)
+            EX0pow, var_0 = self._estimate(E[:, 0], n_shots_data_list, -1, order=4, Return_var=True, unbiased=True)
+            grad_data_exact = 2.0 * (-y_eval * EX0pow_exact[0] + w * EX0pow_exact[1])
+        else:
+            EX0pow, var_0 = self._estimate(E[:, 0], n_shots_data_list, min_approx, order=4, Return_var=True, unbiased=True)
+        EX0_list = EX0pow[0]
+        self.cache_train_pred = w * EX0_list
+        self.cache_y_train_eval = y_eval
+        grad_data_list[-1] = 2.0 * (-y_eval * EX0_list + w * EX0pow[1])
+        grad[-1] = np.mean(grad_data_list[-1])
+        if debug:
+            gvar_list_EV[-1] = self._estimate_MSEgrad_mean_condVar(y_eval, EX0pow_exact, w=w, Scale_para=True,
+                                                                   var_0=var_0_exact, n0=n0, second_order=second_order)
+            gvar_list_b[-1] = self._estimate_MSEgrad_Var_condMean(y_eval, grad_data_exact, size, EX0pow_exact, w=w, Scale_para=True)
+        else:
+            gvar_list_EV[-1] = self._estimate_MSEgrad_mean_condVar(y_eval, EX0pow, w=w, Scale_para=True, var_0=var_0,
+                                                                   n0=n0, second_order=second_order)
+            gvar_list_EV0[-1] = gvar_list_EV[-1]
+            # the reference passes the whole (n_params, B) matrix here (myQNNs_base.py:1488)
+            gvar_list_b[-1] = self._estimate_MSEgrad_Var_condMean(y_eval, grad_data_list, size, EX0pow, w=w, Scale_para=True)
+        for i in range(len(params) - 1):
+            n_shots_data_list = np.floor(n_shots_list[i] * wt_dist).astype(int)
+            Ep, Em = E[:, 1 + 2 * i], E[:, 2 + 2 * i]
+            if debug:
+                EXp_exact, var_p_exact = self._estimate(Ep, n_shots_data_list, -10, order=2, Return_var=True, unbiased=True)
+                EXm_exact, var_m_exact = self._estimate(Em, n_shots_data_list, -10, order=2, Return_var=True, unbiased=True)
+                EXp, var_p = self._estimate(Ep, n_shots_data_list, -1, order=2, Return_var=True, unbiased=True)
+                EXm, var_m = self._estimate(Em, n_shots_data_list, -1, order=2, Return_var=True, unbiased=True)
+                grad_data_exact = (w * EX0pow_exact[0] - y_eval) * w * (EXp_exact[0] - EXm_exact[0])
+            else:
+                EXp, var_p = self._estimate(Ep, n_shots_data_list, min_approx, order=2, Return_var=True, unbiased=True)
+                EXm, var_m = self._estimate(Em, n_shots_data_list, min_approx, order=2, Return_var=True, unbiased=True)
+            grad_data_list[i] = (w * EX0_list - y_eval) * w * (EXp[0] - EXm[0])
+            grad[i] = np.mean(grad_data_list[i])
+            if debug:
+                gvar_list_EV[i] = self._estimate_MSEgrad_mean_condVar(
+                    y_eval, EX0pow_exact, w=w, second_order=second_order, n0=n0, var_0=var_0_exact, Scale_para=False,
+                    Eppow_data_list=EXp_exact, Empow_data_list=EXm_exact, var_p=var_p_exact, var_m=var_m_exact)[0]
+                gvar_list_b[i] = self._estimate_MSEgrad_Var_condMean(y_eval, grad_data_exact, size, EX0pow_exact, w=w,
+                                                                     Scale_para=False, Eppow_data_list=EXp_exact,
+                                                                     Empow_data_list=EXm_exact)
+            else:
+                EV, EVi, EV0 = self._estimate_MSEgrad_mean_condVar(
+                    y_eval, EX0pow, w=w, second_order=second_order, n0=n0, var_0=var_0, Scale_para=False,
+                    Eppow_data_list=EXp, Empow_data_list=EXm, var_p=var_p, var_m=var_m)
+                gvar_list_EV[i], gvar_list_EVi[i], gvar_list_EV0[i] = EV, EVi, EV0
+                gvar_list_b[i] = self._estimate_MSEgrad_Var_condMean(y_eval, grad_data_list, size, EX0pow, w=w, Scale_para=False,
+                                                                     Eppow_data_list=EXp, Empow_data_list=EXm)
+        return {"grad": grad, "gvar_list_EV": gvar_list_EV, "gvar_list_EVi": gvar_list_EVi,
+                "gvar_list_EV0": gvar_list_EV0, "gvar_list_b": gvar_list_b, "grad_data_list": grad_data_list}
+
+    def _outcomes(self, exact, n_s):
+        """Raw +-1 outcome arrays (one per sample) drawn from the exact Z0 distribution
+        (stands in for _sample_outcomes_sum_Z_all_data, myQNNs_base.py:749-765)."""
+        self.circuit_counter[0] += len(exact)
+        self.call_counter[0] += len(exact)
+        self.shots_counter[0] += int(np.sum(n_s))
+        out = []
+        for e, n in zip(exact, n_s):
+            out.append(np.where(np.random.random(int(n)) < 0.5 * (1.0 - e), -1, 1))
+        return out, np.array([o.sum() for o in out], dtype=float)
+
+    def MSE_iEval_iRandom(self, params, n_shots_list, option_weight=None):
+        """myQNNs_base.py:1619-1666: per component an independent multinomial shot
+        allocation over the whole training set (gCANS / Refoqus)."""
+        grad = np.zeros_like(params)
+        gvar_list = np.zeros_like(params)
+        if option_weight is None:
+            wt_dist = self._uniform_wt_dist.copy()
+        else:
+            wt_dist = np.array(option_weight) / np.sum(option_weight)
+        w = params[-1]
+        M_tot = self.num_train_data
+        theta = np.asarray(params[:self.n_c_params], dtype=np.float64)
+        for i in range(len(params)):
+            n_shots_data_list = np.random.multinomial(n_shots_list[i], wt_dist)
+            sel = np.nonzero(n_shots_data_list != 0)[0].astype(np.int32)
+            y_eval = self.y_train[sel]
+            n_shots_eval = n_shots_data_list[sel]
+            n = n_shots_list[i]
+            if i == len(params) - 1:
+                n_shots_eval = n_shots_eval * 2
+                exact = self._expect_all(params, which="train", idx=sel)
+                outcomes0, outsum = self._outcomes(exact, n_shots_eval)
+                grad[i] = np.sum(w * (outsum ** 2 - n_shots_eval) / (2 * n * (n - 1) / M_tot + n) - y_eval * outsum / n)
+                gvar_list[i] = self._direct_sample_MSEgrad_varUB_whole(y_eval, outcomes0, w=w, Scale_para=True)
+            else:
+                E = len(sel)
+                si = np.tile(sel, 3)
+                sp = np.concatenate([np.full(E, -1), np.full(E, i), np.full(E, i)]).astype(np.int32)
+                sv = np.concatenate([np.zeros(E), np.full(E, 0.5 * np.pi), np.full(E, -0.5 * np.pi)])
+                e, _ = self.circuit.eval_batch(theta, self._handle("train"), sample_idx=si, shift_param=sp, shift_val=sv,
+                                               obs_list=self._obs_list())
+                e = _np(e)[:, 0]
+                outcomes0, outsum0 = self._outcomes(e[:E], n_shots_eval)
+                outcomes_p, outsum_p = self._outcomes(e[E:2 * E], n_shots_eval)
+                outcomes_m, outsum_m = self._outcomes(e[2 * E:], n_shots_eval)
+                grad[i] = np.sum((w * outsum0 / (n + n * (n - 1) / M_tot) - y_eval / n) * (outsum_p - outsum_m) * w)
+                gvar_list[i] = self._direct_sample_MSEgrad_varUB_whole(y_eval, outcomes0, w=w, Scale_para=False,
+                                                                       outcomes_whole_p=outcomes_p, outcomes_whole_m=outcomes_m)
+        return {"grad": grad, "gvar_list": gvar_list}
+
+
+class myQNN_regression(myQNN_base):
+    """vqa/QNN/myQNNs_regression.py:256 is the same regressor kept as a standalone class."""
