@@ -7,7 +7,15 @@ One "step" = one pass of the hot path over the batch: B * (2P+1) circuit
 evaluations on the GPU (vqa_psr_full_dev, inputs resident in HBM), the
 per-sample products and batch means that turn them into the regressor's MSE
 gradient (vqa/QNN/myQNNs_base.py:1378-1394), and for N > 1 one all-reduce of the
-P+1 gradient sums over RCCL.
+P+1 gradient sums over RCCL.  Every one of the B * (2P+1) expectation values is
+computed and written each step; the sweep kernel shares the unshifted prefix of
+a sample's circuit between its shifted evaluations ("prefix_reuse").
+
+The roofline object prices the sweep kernel against the FP64 vector unit, the
+resource rocprof shows it bound by (state vectors of 12 qubits live in
+registers and LDS, HBM only sees inputs and results).  "achieved" counts the
+ALGORITHMIC work of the submitted, unfused gate list, so it can exceed the
+peak: the engine fuses gates, drops redundant phases and reuses prefixes.
 
 Usage: python bench.py --gpus N --steps K --warmup W
 (N > 1: launched by torch.distributed.run, one rank per GPU.)
@@ -27,10 +35,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# peaks from the MI355X micro-architecture guide: LDS ds_read_b64/b128 with every
-# CU streaming ~150 TB/s aggregate; FP64 vector 78.6 TFLOP/s (half the 157.3 FP32)
-LDS_PEAK_GBS = 150_000.0
+# vendor peaks (MI355X): FP64 vector 78.6 TFLOP/s; HBM3E 8 TB/s; LDS 128 B/clk/CU
+# x 256 CUs x 2.4 GHz.  The same three ceilings are measured on the box by
+# vqa_amd/csrc/peaks.hip and printed beside these.
 FP64_PEAK_TFLOPS = 78.6
+HBM_PEAK_GBS = 8000.0
+LDS_PEAK_GBS = 128 * 256 * 2.4
 
 WORKLOADS = {
     # name: (n_qubits, depth, batch per GPU)
@@ -82,6 +92,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
     from vqa_amd import LearningCircuit, Observable, _lib, create_ibm_HEA_ansatz
+    from vqa_amd.distributed import sharded_mse_gradient
 
     n, d, B = WORKLOADS[args.workload]
     if args.batch:
@@ -115,25 +126,31 @@ def main():
     d_theta = torch.from_numpy(theta).to(dev)
     d_y = torch.from_numpy(y).to(dev)
     d_out = torch.empty((B, K, 1), dtype=torch.float64, device=dev)
-    grad_sums = torch.zeros(P + 1, dtype=torch.float64, device=dev)
+    measured = measured_peaks(local_rank) if rank == 0 else {}
 
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
+    class Timed:
+        """the circuit with its sweep bracketed by events on torch's current stream
+        (the stream the library launches on)"""
+
+        def __init__(self):
+            self.i = None
+
+        def psr_full(self, *a, **k):
+            if self.i is not None:
+                ev0[self.i].record()
+            r = circ.psr_full(*a, **k)
+            if self.i is not None:
+                ev1[self.i].record()
+            return r
+
+    timed = Timed()
+
     def step(i=None):
-        if i is not None:
-            ev0[i].record()
-        circ.psr_full(d_theta, d_in, n_sel=B, obs_list=[z0], out_expect=d_out)
-        if i is not None:
-            ev1[i].record()
-        e = d_out[:, :, 0]
-        e0 = e[:, 0]
-        resid = (w * e0 - d_y) * w
-        grad_sums[:P] = (resid[:, None] * (e[:, 1::2] - e[:, 2::2])).sum(dim=0)
-        grad_sums[P] = (2.0 * (-d_y * e0 + w * e0 * e0)).sum()
-        if world > 1:
-            dist.all_reduce(grad_sums)
-        return grad_sums / (B * world)
+        timed.i = i
+        return sharded_mse_gradient(timed, d_theta, d_in, d_y, w, z0, n_global=B * world, out_expect=d_out)
 
     def fence():
         if world > 1:
@@ -179,31 +196,72 @@ def main():
                             f"batch {B} samples per GPU, full parameter shift ({K} evaluations per sample)",
                 "n_qubits": n, "depth": d, "batch_per_gpu": B, "n_params": P,
                 "evals_per_step_per_gpu": evals, "engine": args.engine or "auto",
-                "prefix_reuse": False,
+                "prefix_reuse": True,
             },
-            "roofline": {
-                "bound": "lds",
-                "achieved": bytes_alg * evals_per_s_kernel / 1e9,
-                "peak": LDS_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": bytes_alg * evals_per_s_kernel / 1e9 / LDS_PEAK_GBS,
-                "traffic": None,
-                "kernel_ms_per_launch": kern_ms,
-                "alg_bytes_per_eval": bytes_alg,
-                "fp64": {
-                    "achieved": flops_alg * evals_per_s_kernel / 1e12,
-                    "peak": FP64_PEAK_TFLOPS,
-                    "unit": "TFLOP/s",
-                    "frac": flops_alg * evals_per_s_kernel / 1e12 / FP64_PEAK_TFLOPS,
-                    "alg_flops_per_eval": flops_alg,
-                },
-            },
+            "roofline": roofline(bytes_alg, flops_alg, evals, kern_ms, measured),
         }
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(circ, theta, ia, P, args.cpu_seconds)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def measured_peaks(device):
+    """This GPU's own ceilings from the micro-benchmarks in vqa_amd/csrc/peaks.hip."""
+    import ctypes as C
+
+    path = os.path.join(ROOT, "vqa_amd", "csrc", "libvqapeaks.so")
+    if not os.path.exists(path):
+        return {}
+    lib = C.CDLL(path)
+    out = {}
+    for key, fn in (("fp64_fma_tflops", "vqa_peak_fp64_fma"), ("lds_gbs", "vqa_peak_lds"), ("hbm_copy_gbs", "vqa_peak_hbm_copy")):
+        v = C.c_double(0.0)
+        if getattr(lib, fn)(C.c_int(device), C.byref(v)) == 0:
+            out[key] = v.value
+    return out
+
+
+def hbm_traffic_per_launch(evals):
+    """HBM bytes per launch of the sweep kernel from the committed rocprofv3 PMC pass
+    of this same command (profiles/hbm_traffic.json: bytes per circuit evaluation,
+    corrected as the micro-architecture guide prescribes); None when absent."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["hbm_bytes_per_eval"] * evals
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def roofline(bytes_alg, flops_alg, evals, kern_ms, measured):
+    per_s = evals / (kern_ms * 1e-3)
+    tflops = flops_alg * per_s / 1e12
+    gbs = bytes_alg * per_s / 1e9
+    r = {
+        "kernel": "k_reg_psr",
+        "bound": "fp64_valu",
+        "achieved": tflops,
+        "peak": FP64_PEAK_TFLOPS,
+        "unit": "TFLOP/s",
+        "frac": tflops / FP64_PEAK_TFLOPS,
+        "traffic": hbm_traffic_per_launch(evals),
+        "kernel_ms_per_launch": kern_ms,
+        "evals_per_launch": evals,
+        "alg_flops_per_eval": flops_alg,
+        "alg_bytes_per_eval": bytes_alg,
+        "note": "algorithmic work of the unfused gate list; > 1 is possible because the engine fuses gates and "
+                "reuses each sample's unshifted prefix; executed-instruction fractions are in profiles/",
+        # the same algorithmic state traffic priced against the two memory levels it could have lived in
+        "lds": {"achieved": gbs, "peak": LDS_PEAK_GBS, "unit": "GB/s", "frac": gbs / LDS_PEAK_GBS},
+        "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS},
+    }
+    if measured:
+        r["measured_peaks"] = measured
+        if "fp64_fma_tflops" in measured:
+            r["frac_of_measured_peak"] = tflops / measured["fp64_fma_tflops"]
+    return r
 
 
 def cpu_baseline(circ, theta, ia, P, seconds):

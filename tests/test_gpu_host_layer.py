@@ -1,0 +1,97 @@
+"""Host layer on the HIP circuit against the same layer on the CPU-oracle
+circuit (same NumPy seed), and against the golden trajectories."""
+import numpy as np
+import pytest
+
+from oracle_circuit import OracleCircuit
+from test_host_layer import run_golden_case
+from vqa_amd import LearningCircuit
+from vqa_amd.qml_utils import create_ibm_HEA_ansatz, create_jerbi_ansatz
+from vqa_amd.qnn_base import myQNN_base
+from vqa_amd.qnn_classifier import myQNN_classifier
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["Adam", "SGD", "SGDM"])
+def test_golden_trajectory_hip_circuit(name):
+    # parameters within 1e-8 of the reference optimizer's trajectory, shot totals exact
+    run_golden_case(name, LearningCircuit, 1e-8)
+
+
+def pair(builder, n, depth, cls, n_train=20, seed=1, **kw):
+    out = []
+    for circuit_cls in (LearningCircuit, OracleCircuit):
+        rng = np.random.default_rng(seed)
+        c = builder(n, depth, circuit_cls=circuit_cls)
+        x = rng.uniform(0, 1, (n_train + 8, n))
+        if cls is myQNN_classifier:
+            y = rng.integers(0, 3, n_train + 8)
+            q = cls(n, c, x[:n_train], y[:n_train], x[n_train:], y[n_train:], **kw)
+            p = rng.uniform(-3, 3, q.n_params)
+        else:
+            q = cls(n, c, min_approx_shots=0, **kw)
+            tp = np.concatenate([rng.uniform(-3, 3, q.n_c_params), [1.2]])
+            y = np.sin(x.sum(axis=1)) + 0 * tp[0]
+            q.set_data(x[:n_train], y[:n_train], x[n_train:], y[n_train:])
+            p = np.concatenate([rng.uniform(-3, 3, q.n_c_params), [0.8]])
+        out.append((q, p))
+    return out
+
+
+@pytest.mark.parametrize("builder,n,depth", [(create_ibm_HEA_ansatz, 6, 2), (create_jerbi_ansatz, 5, 2),
+                                             (create_ibm_HEA_ansatz, 10, 1)])
+def test_regressor_oracles_match(builder, n, depth):
+    (g, p), (o, _) = pair(builder, n, depth, myQNN_base)
+    shots = np.full(g.n_params, 300)
+    assert np.max(np.abs(g.exact_predict(g.x_test, p) - o.exact_predict(o.x_test, p))) < 1e-10
+    a, b = g.exact_MSE(p, ret_both=True), o.exact_MSE(p, ret_both=True)
+    assert abs(a["test"] - b["test"]) < 1e-10 and abs(a["train"] - b["train"]) < 1e-10
+    for fn, kw in [("MSE_grad_eval", dict(mini_batch_size=7)), ("MSE_loss_eval", dict(mini_batch_size=7)),
+                   ("MSE_iEval", dict(mini_batch_size=7))]:
+        res = []
+        for q in (g, o):
+            np.random.seed(77)
+            q.remain_ind = []
+            q.shots_counter[0] = q.call_counter[0] = q.circuit_counter[0] = 0
+            arg = shots if fn != "MSE_loss_eval" else 300
+            res.append((getattr(q, fn)(p, arg, **kw), q.shots_counter[0], q.call_counter[0], q.circuit_counter[0]))
+        assert res[0][1:] == res[1][1:]
+        if isinstance(res[0][0], dict):
+            for k in res[0][0]:
+                assert np.max(np.abs(res[0][0][k] - res[1][0][k])) < 1e-8, k
+        else:
+            assert np.max(np.abs(np.asarray(res[0][0]) - np.asarray(res[1][0]))) < 1e-8
+    # exact mode: no random numbers at all
+    g.remain_ind, o.remain_ind = [], []
+    ge = g.MSE_grad_eval(p, shots, mini_batch_size=len(g.x_train), option_min_approx=-10)
+    oe = o.MSE_grad_eval(p, shots, mini_batch_size=len(o.x_train), option_min_approx=-10)
+    assert np.max(np.abs(ge - oe)) < 1e-10  # full-set means do not depend on the permutation
+
+
+@pytest.mark.parametrize("unbias", [True, False])
+def test_classifier_oracles_match(unbias):
+    (g, p), (o, _) = pair(create_ibm_HEA_ansatz, 6, 1, myQNN_classifier, class_unbias=unbias)
+    assert np.max(np.abs(g.exact_prob_dist_data_by_data(g.x_test, p) - o.exact_prob_dist_data_by_data(o.x_test, p))) < 1e-10
+    a, b = g.exact_predict_error_and_MSE(p), o.exact_predict_error_and_MSE(p)
+    assert all(abs(a[k] - b[k]) < 1e-10 for k in a)
+    idx = np.arange(len(g.x_train))
+    assert np.max(np.abs(g._psr_marginals(p, idx) - o._psr_marginals(p, idx))) < 1e-10
+    shots = np.full(g.n_params, 200)
+    for fn in ("MSE_grad_eval", "CE_grad_eval"):
+        res = []
+        for q in (g, o):
+            np.random.seed(5)
+            q.remain_ind = []
+            res.append(getattr(q, fn)(p, shots, mini_batch_size=6))
+        # same seed, probabilities equal to 1e-10: the drawn counts coincide
+        assert np.max(np.abs(res[0] - res[1])) < 1e-8
+
+
+def test_fit_runs_on_gpu_and_pickles(tmp_path):
+    (g, p), _ = pair(create_ibm_HEA_ansatz, 4, 1, myQNN_base)
+    np.random.seed(0)
+    g.compile(optimizer="Adam", hpara=dict(LR_rule=0.05, s_list_rule=np.full(g.n_params, 100), batch_size_rule=6), init_params=p)
+    res = g.fit(options=dict(max_iter=15), auto_save=True, save_directory=str(tmp_path))
+    assert res["func_evol"][-1]["train"] < res["func_evol"][0]["train"]
+    assert len(list(tmp_path.iterdir())) == 1
