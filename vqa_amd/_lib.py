@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libvqahip.so")
+# VQA_HIP_LIBRARY: another build of the same ABI (the section-timing build of tools/section_profile.py)
+LIB_PATH = os.environ.get("VQA_HIP_LIBRARY") or os.path.join(_HERE, "csrc", "libvqahip.so")
 
 OK, EINVAL, ENOMEM, EHIP, EUNSUPPORTED, ENODEVICE = 0, -1, -2, -3, -4, -5
 

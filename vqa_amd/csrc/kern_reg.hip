@@ -6,9 +6,12 @@
 //   - preparation: every fused 2x2 is multiplied out from its angle sources,
 //     split into RZ RY RZ, and its phases are merged into the diagonal stages'
 //     phase tables (all in LDS);
-//   - real rotations on register bits are pure FMA work; on lane bits the
-//     partner amplitude comes through DPP / swizzle moves; qubits on wave bits
-//     are brought into registers by a conflict-free transposition through LDS;
+//   - real rotations on register bits are three in-place fused multiply-adds
+//     per amplitude pair; on lane bits the partner amplitude comes through DPP /
+//     swizzle moves and the update is one fused multiply-add (the common
+//     1/cos or 1/sin factor is left out and divided away at measurement);
+//     qubits on wave bits are brought into registers by a conflict-free
+//     transposition through LDS;
 //   - diagonal stages are one complex multiply per amplitude by a 16-entry
 //     table built per thread, with CZ / Z signs folded in from per-thread masks;
 //   - the Z-basis observables and the low-bit marginal are reduced in place.
@@ -29,6 +32,23 @@
 
 namespace vqa {
 
+// Ablation switches for tools/section_profile.py: only in the separately built
+// libvqahip_prof.so (-DVQA_PROF).  VQA_ABLATE (environment, bit mask) switches
+// parts of the sweep kernel off so that their cost shows as a time difference;
+// results are then wrong on purpose.  bits 0..3: transpositions, register-bit
+// rotations, lane-bit rotations, diagonal stages; 4: measurement; 5: recomputing
+// the shifted 2x2; 6: checkpoint loads.
+// waves per SIMD the sweep kernel is register-budgeted for
+#ifndef VQA_WAVES
+#define VQA_WAVES 3
+#endif
+
+#ifdef VQA_PROF
+#define VQA_ABL(a, bit) (((a).ablate >> (bit)) & 1)
+#else
+#define VQA_ABL(a, bit) 0
+#endif
+
 namespace {
 
 struct RegArgs {
@@ -43,6 +63,10 @@ struct RegArgs {
     double* out_expect;
     double* out_marginal;
     double2* ckpt;     // sweep: per-workgroup checkpoint area
+    unsigned* next;    // sweep: work counter (zero at launch); workgroups take samples from it
+#ifdef VQA_PROF
+    int ablate;
+#endif
 };
 
 struct cplx {
@@ -118,10 +142,17 @@ __device__ __forceinline__ double elem_angle_c(const VQA_CAS ElemGate* g, const 
     return g->coef * v + g->offset;
 }
 
-// Fused 2x2 of U-entry u -> e^{i d} RZ(al) RY(be) RZ(ga):
-// cs = (cos, sin)(be/2) >= 0, A = e^{i al/2}, G = e^{i ga/2}.
+// Fused 2x2 of U-entry u -> e^{i d} RZ(al) RY(be) RZ(ga) with c, s = (cos, sin)(be/2)
+// >= 0, A = e^{i al/2}, G = e^{i ga/2}.  The table entry m the rotation code reads:
+//   register bit:            (tan(be/4), s)   three shears, exact
+//   lane bit, !SCALED:       (c, s)           x <- c x +- s partner
+//   lane bit, SCALED, c >= s: (s/c, 0)        x <- x +- (s/c) partner        (state / c)
+//   lane bit, SCALED, c <  s: (c/s, 1)        x <- +-(c/s) x + partner       (state / s, and a
+//       sign flip of the |1> half, which is a Z after the rotation: RZ(al) Z = i RZ(al - pi),
+//       so A is multiplied by -i)
+template <bool SCALED>
 __device__ __forceinline__ void compute_uentry(const Prog& pp, int u, const double* theta, const double* row,
-                                               int sparam, double sval, double2& cs, cplx& A, cplx& G) {
+                                               int sparam, double sval, double2& m, cplx& A, cplx& G) {
     const int ubegin = pp.uent[u].begin, ucount = pp.uent[u].count;
     cplx m00 = { 1, 0 }, m01 = { 0, 0 }, m10 = { 0, 0 }, m11 = { 1, 0 };
     for (int j = 0; j < ucount; ++j) {
@@ -167,15 +198,25 @@ __device__ __forceinline__ void compute_uentry(const Prog& pp, int u, const doub
     } else {
         A = Yp; G = { 1, 0 };
     }
-    cs = make_double2(a00 * inv, a01 * inv);
+    const double c = a00 * inv, sn = a01 * inv;
+    if (!pp.uent[u].on_lane) {
+        m = make_double2(sn / (1.0 + c), sn);
+    } else if (!SCALED) {
+        m = make_double2(c, sn);
+    } else if (c >= sn) {
+        m = make_double2(sn / c, 0.0);
+    } else {
+        m = make_double2(c / sn, 1.0);
+        A = { A.y, -A.x };
+    }
 }
 
 // Per-instance preparation of the LDS tables of the S states of a workgroup:
-// mat[u] = (cos, sin)(beta/2) of every fused 2x2, ph1 / ph2 = phase tables of the
+// mat[u] = rotation data of every fused 2x2 (see compute_uentry), ph1 / ph2 = phase tables of the
 // diagonal stages with the RZ factors of the neighbouring 2x2s merged in.
 // Instance of state s2 is e0 + s2 (explicit list) or the unshifted circuit of
 // sample e0 + s2 (sweep).
-template <bool SWEEP>
+template <bool SWEEP, bool SCALED>
 __device__ __forceinline__ void prep_tables(const RegArgs& a, const Prog& pp, double2* tabs, int64_t e0, int S,
                                             int NU, int N1, int N2, int tid, int nthr) {
     const int tab_stride = NU + N1 + N2;
@@ -226,7 +267,7 @@ __device__ __forceinline__ void prep_tables(const RegArgs& a, const Prog& pp, do
             const double* row = a.input + (size_t)b * a.n_input;
             double2 cs;
             cplx A, G;
-            compute_uentry(pp, u, a.theta, row, sparam, sval, cs, A, G);
+            compute_uentry<SCALED>(pp, u, a.theta, row, sparam, sval, cs, A, G);
             double2* tb = tabs + (size_t)s2 * tab_stride;
             tb[u] = cs;
             if (d_before >= 0) {
@@ -266,17 +307,24 @@ __device__ __forceinline__ double xor_fetch(double v) {
 // operands so that they are in place by construction: behind the uniform
 // branches of the phase loop anything else makes the register allocator keep
 // a second copy of the state and move it back after every block.
-//   (a0, a1) <- (c a0 + s a1, c a1 - s a0)
-__device__ __forceinline__ void rot_pair(double& a0, double& a1, double c, double s) {
-    double t0, t1;
-    asm("v_mul_f64 %2, %5, %1\n\tv_mul_f64 %3, %5, %0\n\tv_fma_f64 %0, %4, %0, %2\n\tv_fma_f64 %1, %4, %1, -%3"
-        : "+v"(a0), "+v"(a1), "=&v"(t0), "=&v"(t1)
-        : "v"(c), "v"(s));
+//   (a0, a1) <- (c a0 + s a1, c a1 - s a0) as three shears, u = tan(phi/2), s = sin(phi)
+__device__ __forceinline__ void rot_pair(double& a0, double& a1, double u, double s) {
+    asm("v_fma_f64 %0, %2, %1, %0\n\tv_fma_f64 %1, -%3, %0, %1\n\tv_fma_f64 %0, %2, %1, %0"
+        : "+v"(a0), "+v"(a1)
+        : "v"(u), "v"(s));
 }
 //   x <- c x + se p
 __device__ __forceinline__ void lane_upd(double& x, double p, double c, double se) {
     double t;
     asm("v_mul_f64 %1, %4, %2\n\tv_fma_f64 %0, %3, %0, %1" : "+v"(x), "=&v"(t) : "v"(p), "v"(c), "v"(se));
+}
+//   x <- x + te p
+__device__ __forceinline__ void lane_upd_a(double& x, double p, double te) {
+    asm("v_fma_f64 %0, %2, %1, %0" : "+v"(x) : "v"(p), "v"(te));
+}
+//   x <- ke x + p
+__device__ __forceinline__ void lane_upd_b(double& x, double p, double ke) {
+    asm("v_fma_f64 %0, %2, %0, %1" : "+v"(x) : "v"(p), "v"(ke));
 }
 //   (ax + i ay) <- (ax + i ay) (tx + i ty)
 __device__ __forceinline__ void cmul_inplace(double& ax, double& ay, double tx, double ty) {
@@ -287,20 +335,22 @@ __device__ __forceinline__ void cmul_inplace(double& ax, double& ay, double tx, 
 }
 
 template <int J>
-__device__ __forceinline__ void apply_ureg(double2 (&amp)[kRegAmps], double c, double s) {
+__device__ __forceinline__ void apply_ureg(double2 (&amp)[kRegAmps], double u, double s) {
 #pragma unroll
     for (int r = 0; r < kRegAmps; ++r) {
         if (!(r & (1 << J))) {
             const int r1 = r | (1 << J);
-            rot_pair(amp[r].x, amp[r1].x, c, s);
-            rot_pair(amp[r].y, amp[r1].y, c, s);
+            rot_pair(amp[r].x, amp[r1].x, u, s);
+            rot_pair(amp[r].y, amp[r1].y, u, s);
         }
     }
 }
 
-template <int LB>
-__device__ __forceinline__ void apply_ulane(double2 (&amp)[kRegAmps], double c, double s, int lane) {
-    const double se = flip_if(s, (unsigned)(lane >> LB) & 1u);
+// FORM: 0 = x <- m0 x +- m1 partner; 1 = x <- x +- m0 partner; 2 = x <- +-m0 x + partner
+template <int LB, int FORM>
+__device__ __forceinline__ void apply_ulane(double2 (&amp)[kRegAmps], double m0, double m1, int lane) {
+    const unsigned bit = (unsigned)(lane >> LB) & 1u;
+    const double ce = flip_if(FORM == 0 ? m1 : m0, bit);
     // the cross-lane moves below read registers that the previous block wrote
     // from inline assembly, which the compiler's hazard padding does not see
     __builtin_amdgcn_sched_barrier(0);
@@ -310,8 +360,16 @@ __device__ __forceinline__ void apply_ulane(double2 (&amp)[kRegAmps], double c, 
     for (int r = 0; r < kRegAmps; ++r) {
         const double pr = xor_fetch<LB>(amp[r].x);
         const double pi = xor_fetch<LB>(amp[r].y);
-        lane_upd(amp[r].x, pr, c, se);
-        lane_upd(amp[r].y, pi, c, se);
+        if constexpr (FORM == 0) {
+            lane_upd(amp[r].x, pr, m0, ce);
+            lane_upd(amp[r].y, pi, m0, ce);
+        } else if constexpr (FORM == 1) {
+            lane_upd_a(amp[r].x, pr, ce);
+            lane_upd_a(amp[r].y, pi, ce);
+        } else {
+            lane_upd_b(amp[r].x, pr, ce);
+            lane_upd_b(amp[r].y, pi, ce);
+        }
     }
 }
 
@@ -324,9 +382,14 @@ struct Ctx {
     const unsigned short* smask;  // LDS: [sign table][thread] 16-bit sign masks
     int T, t, tid, lane, nthr;
     int xc_id, xc_wt, xc_rt;      // cached per-thread offsets of one transposition descriptor
+#ifdef VQA_PROF
+    int flag_mask;
+#endif
 };
 
-// One transposition through LDS (descriptor xid).
+// One transposition through LDS (descriptor xid).  Register bit 3 keeps its
+// place, so the halves of the state with that bit 0 / 1 go through the same
+// half-size buffer one after the other.
 __device__ __forceinline__ void do_xpose(double2 (&amp)[kRegAmps], const Prog& pp, Ctx& cx, int xid) {
     const VQA_CAS XDesc* xd = pp.xdesc + xid;
     if (xid != cx.xc_id) {
@@ -341,20 +404,23 @@ __device__ __forceinline__ void do_xpose(double2 (&amp)[kRegAmps], const Prog& p
         cx.xc_rt = rt;
     }
     const int wt = cx.xc_wt, rt = cx.xc_rt;
-    const int w0 = xd->wconst[0], w1 = xd->wconst[1], w2 = xd->wconst[2], w3 = xd->wconst[3];
-    const int r0 = xd->rconst[0], r1 = xd->rconst[1], r2 = xd->rconst[2], r3 = xd->rconst[3];
+    const int w0 = xd->wconst[0], w1 = xd->wconst[1], w2 = xd->wconst[2];
+    const int r0 = xd->rconst[0], r1 = xd->rconst[1], r2 = xd->rconst[2];
 #pragma unroll
-    for (int r = 0; r < kRegAmps; ++r) {
-        const int off = wt ^ ((r & 1) ? w0 : 0) ^ ((r & 2) ? w1 : 0) ^ ((r & 4) ? w2 : 0) ^ ((r & 8) ? w3 : 0);
-        *(double2*)(cx.xbuf + off) = amp[r];
-    }
-    __syncthreads();
+    for (int half = 0; half < 2; ++half) {
 #pragma unroll
-    for (int r = 0; r < kRegAmps; ++r) {
-        const int off = rt ^ ((r & 1) ? r0 : 0) ^ ((r & 2) ? r1 : 0) ^ ((r & 4) ? r2 : 0) ^ ((r & 8) ? r3 : 0);
-        amp[r] = *(const double2*)(cx.xbuf + off);
+        for (int r = 0; r < kRegAmps / 2; ++r) {
+            const int off = wt ^ ((r & 1) ? w0 : 0) ^ ((r & 2) ? w1 : 0) ^ ((r & 4) ? w2 : 0);
+            *(double2*)(cx.xbuf + off) = amp[r + 8 * half];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < kRegAmps / 2; ++r) {
+            const int off = rt ^ ((r & 1) ? r0 : 0) ^ ((r & 2) ? r1 : 0) ^ ((r & 4) ? r2 : 0);
+            amp[r + 8 * half] = *(const double2*)(cx.xbuf + off);
+        }
+        __syncthreads();
     }
-    __syncthreads();
 }
 
 // One diagonal stage (descriptor did).
@@ -435,16 +501,21 @@ __device__ __forceinline__ void do_diag(double2 (&amp)[kRegAmps], const Prog& pp
 // diagonal stage (resuming from a checkpoint taken in front of it).  When ckpt
 // != nullptr the state in front of every diagonal stage d is stored at
 // ckpt[(d * 16 + r) * nthr + tid].
+template <bool SCALED>
 __device__ __forceinline__ void run_phases(double2 (&amp)[kRegAmps], const Prog& pp, Ctx& cx, int p0,
                                            bool diag_only_first, double2* ckpt) {
     const VQA_CAS PhaseOp* ph = pp.phases;
     int first_mask = diag_only_first ? (PH_DIAG | PH_END) : -1;
     for (int p = p0;; ++p) {
+#ifdef VQA_PROF
+        const int flags = ph[p].flags & first_mask & cx.flag_mask;
+#else
         const int flags = ph[p].flags & first_mask;
+#endif
         first_mask = -1;
         if (flags & PH_END) break;
         if (flags & PH_XPOSE) do_xpose(amp, pp, cx, ph[p].xdesc);
-        // rotations: the (cos, sin) of the next slot is fetched while the current one runs
+        // rotations: the table entry of the next slot is fetched while the current one runs
         double2 cs = cx.mat[ph[p].ent[0]], csn;
 #define VQA_REG_SLOT(J)                                           \
         csn = cx.mat[ph[p].ent[J + 1]];                           \
@@ -452,9 +523,18 @@ __device__ __forceinline__ void run_phases(double2 (&amp)[kRegAmps], const Prog&
         cs = csn;
         VQA_REG_SLOT(0) VQA_REG_SLOT(1) VQA_REG_SLOT(2) VQA_REG_SLOT(3)
 #undef VQA_REG_SLOT
+        // (with one state per workgroup the two scaled forms are separate optional
+        // blocks, not an if / else: each block then updates the amplitudes in place)
 #define VQA_LANE_SLOT(LB)                                                  \
         csn = cx.mat[ph[p].ent[LB + 5 < 10 ? LB + 5 : 9]];                 \
-        if (flags & (PH_ULANE0 << LB)) apply_ulane<LB>(amp, cs.x, cs.y, cx.lane); \
+        if constexpr (!SCALED) {                                           \
+            if (flags & (PH_ULANE0 << LB)) apply_ulane<LB, 0>(amp, cs.x, cs.y, cx.lane); \
+        } else {                                                           \
+            const int form_b = __builtin_amdgcn_readfirstlane(__double2hiint(cs.y)); \
+            const int run = flags & (PH_ULANE0 << LB);                     \
+            if (run && form_b == 0) apply_ulane<LB, 1>(amp, cs.x, cs.y, cx.lane); \
+            if (run && form_b != 0) apply_ulane<LB, 2>(amp, cs.x, cs.y, cx.lane); \
+        }                                                                  \
         cs = csn;
         VQA_LANE_SLOT(0) VQA_LANE_SLOT(1) VQA_LANE_SLOT(2) VQA_LANE_SLOT(3) VQA_LANE_SLOT(4) VQA_LANE_SLOT(5)
 #undef VQA_LANE_SLOT
@@ -469,16 +549,25 @@ __device__ __forceinline__ void run_phases(double2 (&amp)[kRegAmps], const Prog&
     }
 }
 
-// Z-basis observables and the low-bit marginal of the state held in amp;
-// instance index e, written by the thread with t == 0.
+// Z-basis observables and the low-bit marginal of the state held in amp, which
+// may carry any common factor: every value is divided by the squared norm.
+// Instance index e, written by the thread with t == 0.
 __device__ __forceinline__ void measure(const double2 (&amp)[kRegAmps], const RegArgs& a, const Ctx& cx, unsigned kt,
                                         const unsigned (&krb)[kRegBits], double* red, int64_t e, bool live,
                                         bool valid) {
     const double nanv = __longlong_as_double(0x7ff8000000000000LL);
     const int nq = a.obs.n_obs + (a.n_marg_bits > 0 ? (1 << a.n_marg_bits) : 0);
-    const int wave = cx.tid >> 6;
+    const int wave = cx.tid >> 6, nwave = cx.nthr >> 6;
+    double pr[kRegAmps];
+#pragma unroll
+    for (int r = 0; r < kRegAmps; ++r) pr[r] = amp[r].x * amp[r].x + amp[r].y * amp[r].y;
+    double inv_norm = 1.0;
     for (int q = 0; q < nq; ++q) {
-        double acc = 0.0;
+        double acc = 0.0, nrm = 0.0;
+        if (q == 0) {
+#pragma unroll
+            for (int r = 0; r < kRegAmps; ++r) nrm += pr[r];
+        }
         if (q < a.obs.n_obs) {
             for (int tm = a.obs.off[q]; tm < a.obs.off[q + 1]; ++tm) {
                 const unsigned z = (unsigned)a.obs.z[tm];
@@ -490,8 +579,7 @@ __device__ __forceinline__ void measure(const double2 (&amp)[kRegAmps], const Re
 #pragma unroll
                     for (int j = 0; j < kRegBits; ++j)
                         if (r & (1 << j)) rp += __popc(krb[j] & z);
-                    const double pr = amp[r].x * amp[r].x + amp[r].y * amp[r].y;
-                    part += flip_if(pr, rp & 1u);
+                    part += flip_if(pr[r], rp & 1u);
                 }
                 acc += a.obs.coef[tm] * part;
             }
@@ -503,19 +591,30 @@ __device__ __forceinline__ void measure(const double2 (&amp)[kRegAmps], const Re
 #pragma unroll
                 for (int j = 0; j < kRegBits; ++j)
                     if (r & (1 << j)) k |= krb[j];
-                acc += ((k & M1) == m) ? amp[r].x * amp[r].x + amp[r].y * amp[r].y : 0.0;
+                acc += ((k & M1) == m) ? pr[r] : 0.0;
             }
         }
-        // sum over the threads of the state
+        // sum over the threads of the state; the first quantity carries the norm along
         const int lb = cx.T < 6 ? cx.T : 6;
         for (int i = 0; i < lb; ++i) acc += __shfl_xor(acc, 1 << i, 64);
+        if (q == 0)
+            for (int i = 0; i < lb; ++i) nrm += __shfl_xor(nrm, 1 << i, 64);
         if (cx.T > 6) {
             __syncthreads();
-            if (cx.lane == 0) red[wave] = acc;
+            if (cx.lane == 0) {
+                red[wave] = acc;
+                if (q == 0) red[16 + wave] = nrm;
+            }
             __syncthreads();
             acc = 0.0;
-            for (int w = 0; w < (cx.nthr >> 6); ++w) acc += red[w];
+            for (int w = 0; w < nwave; ++w) acc += red[w];
+            if (q == 0) {
+                nrm = 0.0;
+                for (int w = 0; w < nwave; ++w) nrm += red[16 + w];
+            }
         }
+        if (q == 0) inv_norm = 1.0 / nrm;
+        acc *= inv_norm;
         if (cx.t == 0 && live) {
             if (q < a.obs.n_obs) a.out_expect[e * a.obs.n_obs + q] = valid ? acc : nanv;
             else a.out_marginal[(e << a.n_marg_bits) + (q - a.obs.n_obs)] = valid ? acc : nanv;
@@ -556,7 +655,9 @@ __device__ __forceinline__ void thread_constants(const Prog& pp, unsigned short*
 
 // ---- explicit instance list ----------------------------------------------------------
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_reg_eval(RegArgs a) {
+__global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : VQA_WAVES) void k_reg_eval(RegArgs a) {
+    // blocks above one wave hold a single state: the scaled lane rotations apply
+    constexpr bool SCALED = BLOCK > 64;
     extern __shared__ double2 smem[];
     const Prog pp = load_prog(a.prog);
     const int n = pp.H->n, T = pp.H->T, S = pp.H->S;
@@ -567,8 +668,8 @@ __global__ __launch_bounds__(BLOCK) void k_reg_eval(RegArgs a) {
     const int t = tid & ((1 << T) - 1);   // thread bits of the amplitude index
 
     double2* tabs = smem;                                 // S * tab_stride
-    double2* xbuf = tabs + (size_t)S * tab_stride;        // 2^n slots when the program transposes
-    double* red = (double*)(xbuf + (pp.H->has_xpose ? ((size_t)1 << n) : 0));  // 64 doubles
+    double2* xbuf = tabs + (size_t)S * tab_stride;        // 2^(n-1) slots when the program transposes
+    double* red = (double*)(xbuf + (pp.H->has_xpose ? ((size_t)1 << (n - 1)) : 0));  // 64 doubles
     unsigned short* smask = (unsigned short*)(red + 64);  // n_sign * BLOCK
 
     Ctx cx;
@@ -579,6 +680,9 @@ __global__ __launch_bounds__(BLOCK) void k_reg_eval(RegArgs a) {
     cx.smask = smask;
     cx.T = T; cx.t = t; cx.tid = tid; cx.lane = tid & 63; cx.nthr = BLOCK;
     cx.xc_id = -1; cx.xc_wt = 0; cx.xc_rt = 0;
+#ifdef VQA_PROF
+    cx.flag_mask = -1;
+#endif
 
     unsigned kt, krb[kRegBits];
     thread_constants<BLOCK>(pp, smask, T, t, tid, kt, krb);
@@ -593,14 +697,14 @@ __global__ __launch_bounds__(BLOCK) void k_reg_eval(RegArgs a) {
             valid = decode_eval(a.spec, e, b_, sp_, sv_);
         }
         __syncthreads();
-        prep_tables<false>(a, pp, tabs, e0, S, NU, N1, N2, tid, BLOCK);
+        prep_tables<false, SCALED>(a, pp, tabs, e0, S, NU, N1, N2, tid, BLOCK);
         __syncthreads();
 
         double2 amp[kRegAmps];
 #pragma unroll
         for (int r = 0; r < kRegAmps; ++r) amp[r] = make_double2(0.0, 0.0);
         if (t == 0) amp[0].x = 1.0;
-        run_phases(amp, pp, cx, 0, false, nullptr);
+        run_phases<SCALED>(amp, pp, cx, 0, false, nullptr);
         measure(amp, a, cx, kt, krb, red, e, live, valid);
     }
 }
@@ -608,8 +712,10 @@ __global__ __launch_bounds__(BLOCK) void k_reg_eval(RegArgs a) {
 // ---- full parameter-shift sweeps ------------------------------------------------------
 // a.E = number of samples; sample j = sel[j] (or j); outputs at instance
 // j * (2P+1) + k.  One state per workgroup (BLOCK = 2^T >= 64 threads).
+// Workgroups draw samples from a shared counter until it passes a.E, so the
+// launch may hold more workgroups than are resident at once.
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_reg_psr(RegArgs a) {
+__global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : VQA_WAVES) void k_reg_psr(RegArgs a) {
     extern __shared__ double2 smem[];
     const Prog pp = load_prog(a.prog);
     const int n = pp.H->n, T = pp.H->T;
@@ -620,7 +726,7 @@ __global__ __launch_bounds__(BLOCK) void k_reg_psr(RegArgs a) {
 
     double2* tabs = smem;
     double2* xbuf = tabs + (size_t)(NU + N1 + N2);
-    double* red = (double*)(xbuf + (pp.H->has_xpose ? ((size_t)1 << n) : 0));
+    double* red = (double*)(xbuf + (pp.H->has_xpose ? ((size_t)1 << (n - 1)) : 0));
     double2* pz = (double2*)(red + 64);                   // 9 entries: 2x2 data at theta, theta +- shift
     unsigned short* smask = (unsigned short*)(pz + 16);
     double2* mat = tabs;
@@ -634,6 +740,10 @@ __global__ __launch_bounds__(BLOCK) void k_reg_psr(RegArgs a) {
     cx.T = T; cx.t = t; cx.tid = tid; cx.lane = tid & 63; cx.nthr = BLOCK;
     cx.xc_id = -1; cx.xc_wt = 0; cx.xc_rt = 0;
 
+#ifdef VQA_PROF
+    cx.flag_mask = ~((a.ablate & 1 ? PH_XPOSE : 0) | (a.ablate & 2 ? PH_UREG0 * 15 : 0) |
+                     (a.ablate & 4 ? PH_ULANE0 * 63 : 0) | (a.ablate & 8 ? PH_DIAG : 0));
+#endif
     unsigned kt, krb[kRegBits];
     thread_constants<BLOCK>(pp, smask, T, t, tid, kt, krb);
 
@@ -641,21 +751,26 @@ __global__ __launch_bounds__(BLOCK) void k_reg_psr(RegArgs a) {
     const int K = 2 * P + 1;
     const double shift = a.spec.shift;
 
-    for (int64_t j = blockIdx.x; j < a.E; j += gridDim.x) {
+    __shared__ unsigned s_next;
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) s_next = atomicAdd(a.next, 1u);
+        __syncthreads();
+        const int64_t j = s_next;
+        if (j >= a.E) break;
         int b = a.spec.sel ? a.spec.sel[j] : (int)j;
         const bool valid = a.spec.B == 0 || (unsigned)b < (unsigned)a.spec.B;
         if (!valid) b = 0;
         const double* row = a.input + (size_t)b * a.n_input;
-
         __syncthreads();
-        prep_tables<true>(a, pp, tabs, j, 1, NU, N1, N2, tid, BLOCK);
+        prep_tables<true, true>(a, pp, tabs, j, 1, NU, N1, N2, tid, BLOCK);
         __syncthreads();
 
         double2 amp[kRegAmps];
 #pragma unroll
         for (int r = 0; r < kRegAmps; ++r) amp[r] = make_double2(0.0, 0.0);
         if (t == 0) amp[0].x = 1.0;
-        run_phases(amp, pp, cx, 0, false, ckpt);
+        run_phases<true>(amp, pp, cx, 0, false, ckpt);
         measure(amp, a, cx, kt, krb, red, j * K, true, valid);
 
         for (int i = 0; i < P; ++i) {
@@ -668,10 +783,10 @@ __global__ __launch_bounds__(BLOCK) void k_reg_psr(RegArgs a) {
             const double coef_sum = ref_count > 0 ? pp.refs[pp.params[i].ref_begin].coef_sum : 0.0;
             // lanes 0..2 work out the fused 2x2 at theta, theta + shift, theta - shift
             __syncthreads();
-            if (kind == 0 && tid < 3) {
+            if (kind == 0 && tid < 3 && !VQA_ABL(a, 5)) {
                 double2 cs;
                 cplx A, G;
-                compute_uentry(pp, index, a.theta, row, tid == 0 ? -1 : i, tid == 1 ? shift : -shift, cs, A, G);
+                compute_uentry<true>(pp, index, a.theta, row, tid == 0 ? -1 : i, tid == 1 ? shift : -shift, cs, A, G);
                 pz[tid * 3 + 0] = cs;
                 pz[tid * 3 + 1] = make_double2(A.x, A.y);
                 pz[tid * 3 + 2] = make_double2(G.x, G.y);
@@ -706,16 +821,18 @@ __global__ __launch_bounds__(BLOCK) void k_reg_psr(RegArgs a) {
                 __syncthreads();
                 int pc0 = 0;
                 if (rdiag >= 0) {
+                    if (!VQA_ABL(a, 6)) {
 #pragma unroll
-                    for (int r = 0; r < kRegAmps; ++r) amp[r] = ckpt[((size_t)rdiag * kRegAmps + r) * BLOCK + tid];
+                        for (int r = 0; r < kRegAmps; ++r) amp[r] = ckpt[((size_t)rdiag * kRegAmps + r) * BLOCK + tid];
+                    }
                     pc0 = rpc;
                 } else {
 #pragma unroll
                     for (int r = 0; r < kRegAmps; ++r) amp[r] = make_double2(0.0, 0.0);
                     if (t == 0) amp[0].x = 1.0;
                 }
-                run_phases(amp, pp, cx, pc0, rdiag >= 0, nullptr);
-                measure(amp, a, cx, kt, krb, red, j * K + 1 + 2 * i + sgn, true, valid);
+                run_phases<true>(amp, pp, cx, pc0, rdiag >= 0, nullptr);
+                if (!VQA_ABL(a, 4)) measure(amp, a, cx, kt, krb, red, j * K + 1 + 2 * i + sgn, true, valid);
                 __syncthreads();
                 if (tid == 0 && kind == 0) {
                     const int d_before = pp.uent[index].d_before, d_after = pp.uent[index].d_after;
@@ -754,6 +871,11 @@ static RegArgs make_args(const EvalCall& call, const void* d_prog) {
     a.out_expect = call.d_out_expect;
     a.out_marginal = call.d_out_marginal;
     a.ckpt = nullptr;
+    a.next = nullptr;
+#ifdef VQA_PROF
+    const char* abl = getenv("VQA_ABLATE");
+    a.ablate = abl ? atoi(abl) : 0;
+#endif
     return a;
 }
 
@@ -769,7 +891,10 @@ int reg_engine_run(const EvalCall& call, const void* d_prog, const RegProgram& P
                                         : (const void*)k_reg_eval<512>;
     VQA_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.lds_bytes));
     const int64_t groups = (call.E + S - 1) / S;
-    const int per_cu = std::max<int>(1, std::min<int>(8, (int)((160 * 1024) / std::max<size_t>(P.lds_bytes, 1))));
+    // resident workgroups per CU: LDS, and the register budget of the launch bounds
+    const int by_regs = (P.hdr.block == 512 ? 2 : VQA_WAVES) * 4 / (P.hdr.block / 64);
+    const int by_lds = (int)((160 * 1024) / std::max<size_t>(P.lds_bytes, 1));
+    const int per_cu = std::max(1, std::min(8, std::min(by_regs, by_lds)));
     const int grid = (int)std::min<int64_t>(groups, (int64_t)256 * per_cu);
     switch (P.hdr.block) {
     case 64: hipLaunchKernelGGL(k_reg_eval<64>, dim3(grid), dim3(64), P.lds_bytes, call.stream, a); break;
@@ -801,9 +926,11 @@ int reg_engine_sweep(const EvalCall& call, const void* d_prog, const RegProgram&
     const int grid = (int)std::min<int64_t>(n_samples, (int64_t)256 * per_cu);
     const size_t ck_bytes = (size_t)grid * std::max(P.hdr.n_ddesc, 1) * ((size_t)16 << P.hdr.n);
     void* ws = nullptr;
-    rc = workspace_get(call.device, ck_bytes, &ws);
+    rc = workspace_get(call.device, ck_bytes + 256, &ws);
     if (rc) return rc;
-    a.ckpt = (double2*)ws;
+    a.next = (unsigned*)ws;
+    a.ckpt = (double2*)((char*)ws + 256);
+    VQA_HIP(hipMemsetAsync(a.next, 0, 256, call.stream));
     const void* fn = P.hdr.block == 64 ? (const void*)k_reg_psr<64>
                    : P.hdr.block == 128 ? (const void*)k_reg_psr<128>
                    : P.hdr.block == 256 ? (const void*)k_reg_psr<256>

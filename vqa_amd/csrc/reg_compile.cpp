@@ -145,6 +145,7 @@ inline int par(uint32_t x) { return __builtin_popcount(x) & 1; }
 // writes in the old layout (8 consecutive lanes -> 8 distinct slots mod 8) and
 // for the 16-byte reads in the new layout (the 16-lane read groups of the LDS
 // -> 16 distinct slots mod 16).  sigma[p'] = old position read by new position p'.
+// Register bit R-1 never moves (sigma[R-1] = R-1).
 std::vector<uint32_t> find_swizzle(int n, const int* sigma) {
     const int R = kRegBits;
     const uint32_t w[3] = { 1u << (R + 0), 1u << (R + 1), 1u << (R + 2) };
@@ -171,12 +172,17 @@ std::vector<uint32_t> find_swizzle(int n, const int* sigma) {
         for (int i = 0; i < 4; ++i) { mr[i] = 0; for (int k = 0; k < 4; ++k) mr[i] |= (uint32_t)par(v[i] & f[k]) << k; }
         if (gf2_rank(mw) == 3 && gf2_rank(mr) == 4 && gf2_rank(f) == 4) ok = true;
     }
-    if (!ok) {  // correct but possibly conflicting: identity slots
-        std::vector<uint32_t> id(n);
-        for (int p = 0; p < n; ++p) id[p] = 1u << p;
+    if (!ok) {  // correct but possibly conflicting: identity slots, register bit R-1 on top
+        std::vector<uint32_t> id;
+        for (int p = 0; p < n; ++p) if (p != R - 1) id.push_back(1u << p);
+        id.push_back(1u << (R - 1));
         return id;
     }
-    for (int p = 0; p < n && (int)f.size() < n; ++p) {
+    // complete to an invertible map with unit vectors; register bit R-1 comes
+    // last, so it alone makes the top slot bit (the two halves of the state
+    // then use the same half-size buffer one after the other)
+    for (int i = 0; i < n && (int)f.size() < n; ++i) {
+        const int p = i < R - 1 ? i : (i < n - 1 ? i + 1 : R - 1);
         std::vector<uint32_t> t = f;
         t.push_back(1u << p);
         if (gf2_rank(t) == (int)t.size()) f = t;
@@ -245,11 +251,15 @@ bool reg_compile(int n, int n_theta, const std::vector<vqa_op>& gate_list, RegPr
     auto emit = [&](int kind, int a, int b) { P.ops.push_back(RegOp{ kind, a, b, 0 }); };
     auto emit_direct = [&](int q, int ue) {
         const int p = lay.pos_of[q];
+        P.uent[ue].on_lane = p >= R;
         if (p < R) emit(ROP_UREG, p, ue);
         else emit(ROP_ULANE, p - R, ue);
     };
     auto cheap = [&](int p) { return p < R || p == R + 0 || p == R + 1 || p == R + 3; };
-    const int cheap_slots[7] = { 0, 1, 2, 3, R + 0, R + 1, R + 3 };
+    // slots a transposition may bring a qubit to: every cheap position but register bit R-1,
+    // which stays where it is so that a transposition can run in two halves
+    const int n_swap_slots = 6;
+    const int cheap_slots[n_swap_slots] = { 0, 1, 2, R + 0, R + 1, R + 3 };
 
     for (int u = 0; u < NU; ++u) {
         std::vector<std::pair<int, int>> byq;  // (position, qubit)
@@ -270,7 +280,7 @@ bool reg_compile(int n, int n_theta, const std::vector<vqa_op>& gate_list, RegPr
                     for (int q : remaining) emit_direct(q, uidx[u][q]);
                     break;
                 }
-                const int nb = (int)std::min<size_t>(7, remaining.size());
+                const int nb = (int)std::min<size_t>(n_swap_slots, remaining.size());
                 int old_pos_of[kMaxPos];
                 memcpy(old_pos_of, lay.pos_of, sizeof(old_pos_of));
                 for (int i = 0; i < nb; ++i) {
@@ -289,6 +299,15 @@ bool reg_compile(int n, int n_theta, const std::vector<vqa_op>& gate_list, RegPr
                     xd.wconst[p] = slot << 4;  // byte offset of a 16-byte slot
                 }
                 for (int p = 0; p < n; ++p) xd.rconst[p] = xd.wconst[sigma[p]];
+                if (sigma[R - 1] != R - 1 || xd.wconst[R - 1] != (16 << (n - 1))) {
+                    *why = "internal: transposition does not split into halves";
+                    return false;
+                }
+                for (int p = 0; p < n; ++p)
+                    if (p != R - 1 && (xd.wconst[p] & (16 << (n - 1)))) {
+                        *why = "internal: transposition slot function mixes the halves";
+                        return false;
+                    }
                 int xid = -1;
                 for (size_t k = 0; k < P.xdesc.size() && xid < 0; ++k)
                     if (!memcmp(&P.xdesc[k], &xd, sizeof(xd))) xid = (int)k;
@@ -496,7 +515,7 @@ bool reg_compile(int n, int n_theta, const std::vector<vqa_op>& gate_list, RegPr
     H.has_xpose = P.n_xpose > 0;
 
     const size_t tab1 = ((size_t)H.n_uent + H.n_d1 + H.n_d2) * 16;
-    const size_t xbuf = H.has_xpose ? ((size_t)16 << n) : 0;
+    const size_t xbuf = H.has_xpose ? ((size_t)8 << n) : 0;  // half of the state at a time
     const size_t fixed = 64 * sizeof(double) + (((size_t)H.n_sign * H.block * 2 + 15) & ~(size_t)15);
     P.lds_bytes = (size_t)H.S * tab1 + xbuf + fixed;
     P.lds_bytes_psr = tab1 + xbuf + fixed + 16 * 16;

@@ -8,9 +8,14 @@
 //            (from CNOT-RZ-CNOT sandwiches), CZ and Z signs.
 // Per evaluation every 2x2 is re-expressed on the device as
 //   e^{i d} RZ(alpha) RY(beta) RZ(gamma),
-// so the dense part applied to the amplitudes is a REAL rotation (4 flops per
-// amplitude instead of 8) and the phases e^{i alpha/2}, e^{i gamma/2} are merged
-// into the neighbouring D-stages.  The global phase is dropped.
+// so the dense part applied to the amplitudes is a REAL rotation and the phases
+// e^{i alpha/2}, e^{i gamma/2} are merged into the neighbouring D-stages.  The
+// global phase is dropped.  On register bits the rotation by phi = beta/2 is
+// three in-place shears (a0 += u a1; a1 -= s a0; a0 += u a1 with u = tan(phi/2)
+// <= 1, s = sin(phi)); on lane bits, where each lane holds one amplitude of the
+// pair, it is ONE fused multiply-add per amplitude with the common factor
+// 1/cos or 1/sin left out, so states are carried unnormalised and the
+// measurement divides by the norm.
 //
 // Amplitude index bits are "positions": 0..R-1 live in registers (2^R
 // amplitudes per thread), R..R+L-1 are lane bits, the rest are wave bits.  A
@@ -76,7 +81,7 @@ struct UEntry {
     int32_t d_before;  // ph1 slot that absorbs e^{i gamma/2} (-1: dropped)
     int32_t d_after;   // ph1 slot that absorbs e^{i alpha/2} (-1: dropped)
     int32_t parity;    // U-stage index & 1 (the two preparation phases)
-    int32_t pad;
+    int32_t on_lane;   // 1: applied while the qubit sits on a lane bit, 0: on a register bit
 };
 
 // one single-qubit phase slot of a D-stage: exp(+i/2 * sum of angle terms) on
