@@ -14,7 +14,9 @@ import sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 VARIANTS = [(0, "full kernel"), (1, "no transpositions"), (2, "no register-bit rotations"), (4, "no lane-bit rotations"),
             (8, "no diagonal stages"), (16, "no measurement"), (32, "no 2x2 recomputation"), (64, "no checkpoint loads"),
-            (15, "no gates at all"), (127, "everything off")]
+            (128, "no table patching"), (512, "shifts one by one (no pairs)"),
+            (1024, "pair measurement: no state load"), (2048, "pair measurement: no reductions"), (15, "no gates at all"), (127, "gates, measurement, 2x2, loads off"),
+            (255, "... and no patching"), (511, "... and no phase loop")]
 
 if os.environ.get("VQA_SECTION_CHILD"):
     import numpy as np

@@ -37,7 +37,9 @@ namespace vqa {
 // parts of the sweep kernel off so that their cost shows as a time difference;
 // results are then wrong on purpose.  bits 0..3: transpositions, register-bit
 // rotations, lane-bit rotations, diagonal stages; 4: measurement; 5: recomputing
-// the shifted 2x2; 6: checkpoint loads.
+// the shifted 2x2; 6: checkpoint loads; 7: patching / restoring the tables; 8: the
+// phase loop of shifted evaluations; 9: run the two shifts one by one instead of as a pair;
+// 10: pair measurement without loading the unshifted state; 11: without its reductions.
 // waves per SIMD the sweep kernel is register-budgeted for
 #ifndef VQA_WAVES
 #define VQA_WAVES 3
@@ -150,9 +152,14 @@ __device__ __forceinline__ double elem_angle_c(const VQA_CAS ElemGate* g, const 
 //   lane bit, SCALED, c <  s: (c/s, 1)        x <- +-(c/s) x + partner       (state / s, and a
 //       sign flip of the |1> half, which is a Z after the rotation: RZ(al) Z = i RZ(al - pi),
 //       so A is multiplied by -i)
+// pparam >= 0: the generator (X, Y or Z) of the rotation that parameter pparam drives is
+// inserted in front of that rotation (derivative direction of the parameter).
+// gp = the unit factor of the exact 2x2 that the engine leaves out: e^{i d}, times i
+// in the second scaled lane form, times G when there is no stage in front to take it.
 template <bool SCALED>
 __device__ __forceinline__ void compute_uentry(const Prog& pp, int u, const double* theta, const double* row,
-                                               int sparam, double sval, double2& m, cplx& A, cplx& G) {
+                                               int sparam, double sval, int pparam, double2& m, cplx& A, cplx& G,
+                                               cplx& gp) {
     const int ubegin = pp.uent[u].begin, ucount = pp.uent[u].count;
     cplx m00 = { 1, 0 }, m01 = { 0, 0 }, m10 = { 0, 0 }, m11 = { 1, 0 };
     for (int j = 0; j < ucount; ++j) {
@@ -170,6 +177,17 @@ __device__ __forceinline__ void compute_uentry(const Prog& pp, int u, const doub
         case VQA_GATE_RX: g00 = { c, 0 }; g01 = { 0, sn }; g10 = { 0, sn }; g11 = { c, 0 }; break;
         case VQA_GATE_RY: g00 = { c, 0 }; g01 = { sn, 0 }; g10 = { -sn, 0 }; g11 = { c, 0 }; break;
         default: /* RZ */ g00 = { c, sn }; g01 = { 0, 0 }; g10 = { 0, 0 }; g11 = { c, -sn }; break;
+        }
+        if (kind >= VQA_GATE_RX && g->src == VQA_SRC_THETA && g->idx == pparam) {
+            const cplx h00 = g00, h01 = g01, h10 = g10, h11 = g11;
+            if (kind == VQA_GATE_RX) {          // g X
+                g00 = h01; g01 = h00; g10 = h11; g11 = h10;
+            } else if (kind == VQA_GATE_RY) {   // g Y,  Y = [[0, -i], [i, 0]]
+                g00 = { -h01.y, h01.x }; g01 = { h00.y, -h00.x };
+                g10 = { -h11.y, h11.x }; g11 = { h10.y, -h10.x };
+            } else {                            // g Z
+                g01 = { -h01.x, -h01.y }; g11 = { -h11.x, -h11.y };
+            }
         }
         // M <- G * M
         const cplx a0 = cmul(g00, m00), a1 = cmul(g01, m10), b0 = cmul(g00, m01), b1 = cmul(g01, m11);
@@ -199,6 +217,8 @@ __device__ __forceinline__ void compute_uentry(const Prog& pp, int u, const doub
         A = Yp; G = { 1, 0 };
     }
     const double c = a00 * inv, sn = a01 * inv;
+    gp = cconj(eid);
+    if (pp.uent[u].d_before < 0) gp = cmul(gp, G);
     if (!pp.uent[u].on_lane) {
         m = make_double2(sn / (1.0 + c), sn);
     } else if (!SCALED) {
@@ -208,6 +228,7 @@ __device__ __forceinline__ void compute_uentry(const Prog& pp, int u, const doub
     } else {
         m = make_double2(c / sn, 1.0);
         A = { A.y, -A.x };
+        gp = { -gp.y, gp.x };
     }
 }
 
@@ -266,8 +287,8 @@ __device__ __forceinline__ void prep_tables(const RegArgs& a, const Prog& pp, do
             decode(e2, b, sparam, sval);
             const double* row = a.input + (size_t)b * a.n_input;
             double2 cs;
-            cplx A, G;
-            compute_uentry<SCALED>(pp, u, a.theta, row, sparam, sval, cs, A, G);
+            cplx A, G, gp;
+            compute_uentry<SCALED>(pp, u, a.theta, row, sparam, sval, -1, cs, A, G, gp);
             double2* tb = tabs + (size_t)s2 * tab_stride;
             tb[u] = cs;
             if (d_before >= 0) {
@@ -373,6 +394,32 @@ __device__ __forceinline__ void apply_ulane(double2 (&amp)[kRegAmps], double m0,
     }
 }
 
+// State images in global memory are [amplitude r][thread] and are moved with buffer
+// instructions: one resource for the workgroup's area, a uniform byte offset per
+// image and amplitude, one 32-bit per-thread offset.  All sixteen accesses of a state
+// are then in flight together (with per-amplitude 64-bit vector addresses the
+// register budget makes the compiler reload an address between any two of them).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void load_state(double2 (&amp)[kRegAmps], __amdgpu_buffer_rsrc_t area, unsigned image_off,
+                                           unsigned nthr, unsigned tid) {
+    const unsigned toff = tid * (unsigned)sizeof(double2);
+#pragma unroll
+    for (int r = 0; r < kRegAmps; ++r) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(area, toff, image_off + r * nthr * (unsigned)sizeof(double2), 0);
+        amp[r] = *(const double2*)&v;
+    }
+}
+__device__ __forceinline__ void store_state(const double2 (&amp)[kRegAmps], __amdgpu_buffer_rsrc_t area,
+                                            unsigned image_off, unsigned nthr, unsigned tid) {
+    const unsigned toff = tid * (unsigned)sizeof(double2);
+#pragma unroll
+    for (int r = 0; r < kRegAmps; ++r) {
+        const double2 d = amp[r];
+        __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4*)&d, area, toff,
+                                               image_off + r * nthr * (unsigned)sizeof(double2), 0);
+    }
+}
+
 // everything the op interpreter needs besides the amplitudes
 struct Ctx {
     const double2* mat;   // LDS tables of this state
@@ -382,6 +429,8 @@ struct Ctx {
     const unsigned short* smask;  // LDS: [sign table][thread] 16-bit sign masks
     int T, t, tid, lane, nthr;
     int xc_id, xc_wt, xc_rt;      // cached per-thread offsets of one transposition descriptor
+    __amdgpu_buffer_rsrc_t area;  // sweep: the workgroup's state images (checkpoints, final state)
+    unsigned image_bytes;         // size of one image
 #ifdef VQA_PROF
     int flag_mask;
 #endif
@@ -499,11 +548,11 @@ __device__ __forceinline__ void do_diag(double2 (&amp)[kRegAmps], const Prog& pp
 
 // Runs phases[p0 ..] to PH_END.  diag_only_first: the first phase starts at its
 // diagonal stage (resuming from a checkpoint taken in front of it).  When ckpt
-// != nullptr the state in front of every diagonal stage d is stored at
-// ckpt[(d * 16 + r) * nthr + tid].
+// is set the state in front of every diagonal stage d is stored as image d of
+// the workgroup's area.
 template <bool SCALED>
 __device__ __forceinline__ void run_phases(double2 (&amp)[kRegAmps], const Prog& pp, Ctx& cx, int p0,
-                                           bool diag_only_first, double2* ckpt) {
+                                           bool diag_only_first, bool ckpt) {
     const VQA_CAS PhaseOp* ph = pp.phases;
     int first_mask = diag_only_first ? (PH_DIAG | PH_END) : -1;
     for (int p = p0;; ++p) {
@@ -540,10 +589,7 @@ __device__ __forceinline__ void run_phases(double2 (&amp)[kRegAmps], const Prog&
 #undef VQA_LANE_SLOT
         if (flags & PH_DIAG) {
             const int did = ph[p].ddesc;
-            if (ckpt) {
-#pragma unroll
-                for (int r = 0; r < kRegAmps; ++r) ckpt[((size_t)did * kRegAmps + r) * cx.nthr + cx.tid] = amp[r];
-            }
+            if (ckpt) store_state(amp, cx.area, (unsigned)did * cx.image_bytes, cx.nthr, cx.tid);
             do_diag(amp, pp, cx, did);
         }
     }
@@ -552,9 +598,9 @@ __device__ __forceinline__ void run_phases(double2 (&amp)[kRegAmps], const Prog&
 // Z-basis observables and the low-bit marginal of the state held in amp, which
 // may carry any common factor: every value is divided by the squared norm.
 // Instance index e, written by the thread with t == 0.
-__device__ __forceinline__ void measure(const double2 (&amp)[kRegAmps], const RegArgs& a, const Ctx& cx, unsigned kt,
-                                        const unsigned (&krb)[kRegBits], double* red, int64_t e, bool live,
-                                        bool valid) {
+__device__ __forceinline__ double measure(const double2 (&amp)[kRegAmps], const RegArgs& a, const Ctx& cx, unsigned kt,
+                                          const unsigned (&krb)[kRegBits], double* red, int64_t e, bool live,
+                                          bool valid) {
     const double nanv = __longlong_as_double(0x7ff8000000000000LL);
     const int nq = a.obs.n_obs + (a.n_marg_bits > 0 ? (1 << a.n_marg_bits) : 0);
     const int wave = cx.tid >> 6, nwave = cx.nthr >> 6;
@@ -620,6 +666,113 @@ __device__ __forceinline__ void measure(const double2 (&amp)[kRegAmps], const Re
             else a.out_marginal[(e << a.n_marg_bits) + (q - a.obs.n_obs)] = valid ? acc : nanv;
         }
     }
+    return 1.0 / inv_norm;   // squared norm of the state as held
+}
+
+// Both shifted values of one parameter from ONE extra state.  With psi the
+// unshifted final state and phi the final state of the circuit that has the
+// parameter's generator inserted in front of its rotation, the states at
+// +-kappa are cos(kappa/2) psi +- i sin(kappa/2) phi, so for a diagonal O
+//   <O>(+-) = cos^2 <O>_psi + sin^2 <O>_phi -+ 2 cos sin Im <psi|O|phi>.
+// amp holds phi (any scale), image psi_image of the area the stored psi (scale^2 = psi_norm), rho the
+// ratio of the unit factors the engine left out of the two runs; e0 = instance
+// index of the unshifted evaluation, e1 that of +kappa (-kappa is e1 + 1).
+__device__ __forceinline__ void measure_pair(double2 (&amp)[kRegAmps], unsigned psi_image, double psi_norm, cplx rho,
+                                             double ck, double sk, const RegArgs& a, const Ctx& cx, unsigned kt,
+                                             const unsigned (&krb)[kRegBits], double* red, int64_t e0, int64_t e1,
+                                             bool valid) {
+    const double nanv = __longlong_as_double(0x7ff8000000000000LL);
+    const int nq = a.obs.n_obs + (a.n_marg_bits > 0 ? (1 << a.n_marg_bits) : 0);
+    const int wave = cx.tid >> 6, nwave = cx.nthr >> 6;
+    double pr[kRegAmps];
+    // amp <- conj(psi) phi, pr <- |phi|^2
+#pragma unroll
+    for (int r = 0; r < kRegAmps; ++r) {
+        const u32x4 pv = __builtin_amdgcn_raw_buffer_load_b128(cx.area, cx.tid * (unsigned)sizeof(double2),
+                                                               psi_image + r * cx.nthr * (unsigned)sizeof(double2), 0);
+        const double2 ps = VQA_ABL(a, 10) ? make_double2(1.0, 0.5) : *(const double2*)&pv;
+        const double2 ph = amp[r];
+        pr[r] = ph.x * ph.x + ph.y * ph.y;
+        amp[r] = make_double2(ps.x * ph.x + ps.y * ph.y, ps.x * ph.y - ps.y * ph.x);
+    }
+    double inv_norm = 1.0, inv_cross = 1.0;
+    for (int q = 0; q < nq; ++q) {
+        double v[4] = { 0.0, 0.0, 0.0, 0.0 };   // sum o |phi|^2, Re / Im sum o conj(psi) phi, norm
+        if (q == 0) {
+#pragma unroll
+            for (int r = 0; r < kRegAmps; ++r) v[3] += pr[r];
+        }
+        if (q < a.obs.n_obs) {
+            for (int tm = a.obs.off[q]; tm < a.obs.off[q + 1]; ++tm) {
+                const unsigned z = (unsigned)a.obs.z[tm];
+                const unsigned tpar = __popc(kt & z);
+                double p0 = 0.0, p1 = 0.0, p2 = 0.0;
+#pragma unroll
+                for (int r = 0; r < kRegAmps; ++r) {
+                    unsigned rp = tpar;
+#pragma unroll
+                    for (int j = 0; j < kRegBits; ++j)
+                        if (r & (1 << j)) rp += __popc(krb[j] & z);
+                    p0 += flip_if(pr[r], rp & 1u);
+                    p1 += flip_if(amp[r].x, rp & 1u);
+                    p2 += flip_if(amp[r].y, rp & 1u);
+                }
+                const double cf = a.obs.coef[tm];
+                v[0] += cf * p0; v[1] += cf * p1; v[2] += cf * p2;
+            }
+        } else {
+            const unsigned m = (unsigned)(q - a.obs.n_obs), M1 = (1u << a.n_marg_bits) - 1;
+#pragma unroll
+            for (int r = 0; r < kRegAmps; ++r) {
+                unsigned k = kt;
+#pragma unroll
+                for (int j = 0; j < kRegBits; ++j)
+                    if (r & (1 << j)) k |= krb[j];
+                const bool in = (k & M1) == m;
+                v[0] += in ? pr[r] : 0.0;
+                v[1] += in ? amp[r].x : 0.0;
+                v[2] += in ? amp[r].y : 0.0;
+            }
+        }
+        const int lb = VQA_ABL(a, 11) ? 0 : (cx.T < 6 ? cx.T : 6);
+        const int nv = q == 0 ? 4 : 3;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < nv)
+                for (int i = 0; i < lb; ++i) v[k] += __shfl_xor(v[k], 1 << i, 64);
+        if (cx.T > 6 && !VQA_ABL(a, 11)) {
+            __syncthreads();
+            if (cx.lane == 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) red[k * 8 + wave] = v[k];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k < nv) {
+                    v[k] = 0.0;
+                    for (int w = 0; w < nwave; ++w) v[k] += red[k * 8 + w];
+                }
+            }
+        }
+        if (q == 0) {
+            inv_norm = 1.0 / v[3];
+            inv_cross = rsqrt(v[3] * psi_norm);
+        }
+        if (cx.t == 0) {
+            const bool is_obs = q < a.obs.n_obs;
+            const size_t o0 = is_obs ? (size_t)e0 * a.obs.n_obs + q : ((size_t)e0 << a.n_marg_bits) + (q - a.obs.n_obs);
+            const size_t o1 = is_obs ? (size_t)e1 * a.obs.n_obs + q : ((size_t)e1 << a.n_marg_bits) + (q - a.obs.n_obs);
+            const size_t step = is_obs ? (size_t)a.obs.n_obs : ((size_t)1 << a.n_marg_bits);
+            double* out = is_obs ? a.out_expect : a.out_marginal;
+            const double base = out[o0];
+            const double im = (rho.x * v[2] + rho.y * v[1]) * inv_cross;   // Im(rho * sum)
+            const double mid = ck * ck * base + sk * sk * v[0] * inv_norm;
+            const double dev = 2.0 * ck * sk * im;
+            out[o1] = valid ? mid - dev : nanv;
+            out[o1 + step] = valid ? mid + dev : nanv;
+        }
+    }
 }
 
 // per-thread constants of a launch: sign masks of every sign table (LDS), and the
@@ -680,6 +833,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : VQA_WAVES) void k_reg_eva
     cx.smask = smask;
     cx.T = T; cx.t = t; cx.tid = tid; cx.lane = tid & 63; cx.nthr = BLOCK;
     cx.xc_id = -1; cx.xc_wt = 0; cx.xc_rt = 0;
+    cx.area = __builtin_amdgcn_make_buffer_rsrc((void*)nullptr, 0, 0, 0x00020000);
+    cx.image_bytes = 0;
 #ifdef VQA_PROF
     cx.flag_mask = -1;
 #endif
@@ -704,7 +859,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : VQA_WAVES) void k_reg_eva
 #pragma unroll
         for (int r = 0; r < kRegAmps; ++r) amp[r] = make_double2(0.0, 0.0);
         if (t == 0) amp[0].x = 1.0;
-        run_phases<SCALED>(amp, pp, cx, 0, false, nullptr);
+        run_phases<SCALED>(amp, pp, cx, 0, false, false);
         measure(amp, a, cx, kt, krb, red, e, live, valid);
     }
 }
@@ -727,7 +882,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : VQA_WAVES) void k_reg_psr
     double2* tabs = smem;
     double2* xbuf = tabs + (size_t)(NU + N1 + N2);
     double* red = (double*)(xbuf + (pp.H->has_xpose ? ((size_t)1 << (n - 1)) : 0));
-    double2* pz = (double2*)(red + 64);                   // 9 entries: 2x2 data at theta, theta +- shift
+    double2* pz = (double2*)(red + 64);                   // 12 entries: 2x2 data at theta and at two variants
     unsigned short* smask = (unsigned short*)(pz + 16);
     double2* mat = tabs;
     double2* ph1 = tabs + NU;
@@ -747,7 +902,10 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : VQA_WAVES) void k_reg_psr
     unsigned kt, krb[kRegBits];
     thread_constants<BLOCK>(pp, smask, T, t, tid, kt, krb);
 
-    double2* ckpt = a.ckpt + (size_t)blockIdx.x * ((size_t)ND << n);
+    // the workgroup's area: ND checkpoints and the unshifted final state, 16 * 2^n bytes each
+    cx.image_bytes = 16u << n;
+    cx.area = __builtin_amdgcn_make_buffer_rsrc((void*)(a.ckpt + (size_t)blockIdx.x * ((size_t)(ND + 1) << n)), 0,
+                                                (ND + 1) * cx.image_bytes, 0x00020000);
     const int K = 2 * P + 1;
     const double shift = a.spec.shift;
 
@@ -770,8 +928,10 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : VQA_WAVES) void k_reg_psr
 #pragma unroll
         for (int r = 0; r < kRegAmps; ++r) amp[r] = make_double2(0.0, 0.0);
         if (t == 0) amp[0].x = 1.0;
-        run_phases<true>(amp, pp, cx, 0, false, ckpt);
-        measure(amp, a, cx, kt, krb, red, j * K, true, valid);
+        run_phases<true>(amp, pp, cx, 0, false, true);
+        // the unshifted final state, for the parameters evaluated as a pair
+        store_state(amp, cx.area, (unsigned)ND * cx.image_bytes, BLOCK, tid);
+        const double psi_norm = measure(amp, a, cx, kt, krb, red, j * K, true, valid);
 
         for (int i = 0; i < P; ++i) {
             const int ref_count = pp.params[i].ref_count;
@@ -781,25 +941,32 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : VQA_WAVES) void k_reg_psr
             const int kind = ref_count > 0 ? pp.refs[pp.params[i].ref_begin].kind : -1;
             const int index = ref_count > 0 ? pp.refs[pp.params[i].ref_begin].index : 0;
             const double coef_sum = ref_count > 0 ? pp.refs[pp.params[i].ref_begin].coef_sum : 0.0;
-            // lanes 0..2 work out the fused 2x2 at theta, theta + shift, theta - shift
+            // pair evaluation: the parameter drives one rotation of a fused 2x2 whose
+            // trailing phase goes into a later diagonal stage (so that both runs end in
+            // the same frame); otherwise the two shifted circuits are run one by one
+            const bool pair = kind == 0 && coef_sum != 0.0 && pp.uent[index].d_after >= 0 && !VQA_ABL(a, 9);
+            const int nrun = pair ? 1 : 2;
+            // lanes 0..2 work out the fused 2x2 at theta and at the variants
             __syncthreads();
-            if (kind == 0 && tid < 3 && !VQA_ABL(a, 5)) {
+            if (kind == 0 && tid < 1 + (pair ? 1 : 2) && !VQA_ABL(a, 5)) {
                 double2 cs;
-                cplx A, G;
-                compute_uentry<true>(pp, index, a.theta, row, tid == 0 ? -1 : i, tid == 1 ? shift : -shift, cs, A, G);
-                pz[tid * 3 + 0] = cs;
-                pz[tid * 3 + 1] = make_double2(A.x, A.y);
-                pz[tid * 3 + 2] = make_double2(G.x, G.y);
+                cplx A, G, gp;
+                compute_uentry<true>(pp, index, a.theta, row, (tid == 0 || pair) ? -1 : i, tid == 1 ? shift : -shift,
+                                     (pair && tid == 1) ? i : -1, cs, A, G, gp);
+                pz[tid * 4 + 0] = cs;
+                pz[tid * 4 + 1] = make_double2(A.x, A.y);
+                pz[tid * 4 + 2] = make_double2(G.x, G.y);
+                pz[tid * 4 + 3] = make_double2(gp.x, gp.y);
             }
-            for (int sgn = 0; sgn < 2; ++sgn) {
+            for (int sgn = 0; sgn < nrun; ++sgn) {
                 // thread 0 patches the entry (old values stay in its registers)
                 double2 old_mat = make_double2(0, 0), old_a = old_mat, old_b = old_mat;
                 __syncthreads();
-                if (tid == 0 && kind == 0) {
+                if (tid == 0 && kind == 0 && !VQA_ABL(a, 7)) {
                     const int d_before = pp.uent[index].d_before, d_after = pp.uent[index].d_after;
-                    const double2 A0 = pz[1], G0 = pz[2], A1 = pz[(1 + sgn) * 3 + 1], G1 = pz[(1 + sgn) * 3 + 2];
+                    const double2 A0 = pz[1], G0 = pz[2], A1 = pz[(1 + sgn) * 4 + 1], G1 = pz[(1 + sgn) * 4 + 2];
                     old_mat = mat[index];
-                    mat[index] = pz[(1 + sgn) * 3];
+                    mat[index] = pz[(1 + sgn) * 4];
                     if (d_before >= 0) {
                         old_a = ph1[d_before];
                         const cplx q = cmul(cmul({ old_a.x, old_a.y }, { G0.x, -G0.y }), { G1.x, G1.y });
@@ -821,20 +988,28 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : VQA_WAVES) void k_reg_psr
                 __syncthreads();
                 int pc0 = 0;
                 if (rdiag >= 0) {
-                    if (!VQA_ABL(a, 6)) {
-#pragma unroll
-                        for (int r = 0; r < kRegAmps; ++r) amp[r] = ckpt[((size_t)rdiag * kRegAmps + r) * BLOCK + tid];
-                    }
+                    if (!VQA_ABL(a, 6)) load_state(amp, cx.area, (unsigned)rdiag * cx.image_bytes, BLOCK, tid);
                     pc0 = rpc;
                 } else {
 #pragma unroll
                     for (int r = 0; r < kRegAmps; ++r) amp[r] = make_double2(0.0, 0.0);
                     if (t == 0) amp[0].x = 1.0;
                 }
-                run_phases<true>(amp, pp, cx, pc0, rdiag >= 0, nullptr);
-                if (!VQA_ABL(a, 4)) measure(amp, a, cx, kt, krb, red, j * K + 1 + 2 * i + sgn, true, valid);
+                if (!VQA_ABL(a, 8)) run_phases<true>(amp, pp, cx, pc0, rdiag >= 0, false);
+                if (!VQA_ABL(a, 4)) {
+                    if (pair) {
+                        const double2 g0 = pz[3], g1 = pz[7];
+                        const cplx rho = cmul({ g1.x, g1.y }, { g0.x, -g0.y });
+                        double sk, ck;
+                        sincos(0.5 * coef_sum * shift, &sk, &ck);
+                        measure_pair(amp, (unsigned)ND * cx.image_bytes, psi_norm, rho, ck, sk, a, cx, kt, krb, red, j * K, j * K + 1 + 2 * i,
+                                     valid);
+                    } else {
+                        measure(amp, a, cx, kt, krb, red, j * K + 1 + 2 * i + sgn, true, valid);
+                    }
+                }
                 __syncthreads();
-                if (tid == 0 && kind == 0) {
+                if (tid == 0 && kind == 0 && !VQA_ABL(a, 7)) {
                     const int d_before = pp.uent[index].d_before, d_after = pp.uent[index].d_after;
                     if (d_after >= 0) ph1[d_after] = old_b;
                     if (d_before >= 0) ph1[d_before] = old_a;
@@ -924,7 +1099,7 @@ int reg_engine_sweep(const EvalCall& call, const void* d_prog, const RegProgram&
     a.E = n_samples;
     const int per_cu = std::max<int>(1, std::min<int>(8, (int)((160 * 1024) / std::max<size_t>(P.lds_bytes_psr, 1))));
     const int grid = (int)std::min<int64_t>(n_samples, (int64_t)256 * per_cu);
-    const size_t ck_bytes = (size_t)grid * std::max(P.hdr.n_ddesc, 1) * ((size_t)16 << P.hdr.n);
+    const size_t ck_bytes = (size_t)grid * (P.hdr.n_ddesc + 1) * ((size_t)16 << P.hdr.n);
     void* ws = nullptr;
     rc = workspace_get(call.device, ck_bytes + 256, &ws);
     if (rc) return rc;

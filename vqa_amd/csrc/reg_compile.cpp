@@ -459,7 +459,15 @@ bool reg_compile(int n, int n_theta, const std::vector<vqa_op>& gate_list, RegPr
                     if (g.src != VQA_SRC_THETA) continue;
                     if (std::find(seen.begin(), seen.end(), g.idx) != seen.end()) continue;
                     seen.push_back(g.idx);
-                    per[g.idx].push_back(PatchRef{ 0, kv.second, 0.0 });
+                    // coef_sum: the coefficient the parameter enters its ONE gate of this entry
+                    // with; 0 when it enters several (no single generator to insert then)
+                    int uses = 0;
+                    double coef = 0.0;
+                    for (int k = 0; k < e.count; ++k) {
+                        const ElemGate& h = P.elems[e.begin + k];
+                        if (h.src == VQA_SRC_THETA && h.idx == g.idx) { ++uses; coef = h.coef; }
+                    }
+                    per[g.idx].push_back(PatchRef{ 0, kv.second, uses == 1 ? coef : 0.0 });
                     first_stage[g.idx] = std::min(first_stage[g.idx], 2 * u);
                 }
             }

@@ -134,7 +134,8 @@ struct XDesc {
 struct PatchRef {
     int32_t kind;     // 0: U-entry `index`; 1: ph1 slot `index`; 2: ph2 entry `index`
     int32_t index;
-    double coef_sum;  // kinds 1, 2: sum of the coefficients the parameter enters the slot with
+    double coef_sum;  // kinds 1, 2: sum of the coefficients the parameter enters the slot with;
+                      // kind 0: coefficient of the one gate of the entry it enters, 0 when several
 };
 struct ParamInfo {
     int32_t ref_begin, ref_count;  // into refs[]
