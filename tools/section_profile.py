@@ -37,10 +37,25 @@ if os.environ.get("VQA_SECTION_CHILD"):
     circ.psr_full(theta, x, n_sel=B, obs_list=obs)
     ev1.record()
     torch.cuda.synchronize()
+    if os.environ.get("VQA_STAMPS"):
+        import ctypes as C
+        from vqa_amd import _lib
+        buf = (C.c_ulonglong * 16)()
+        _lib.lib().vqa_debug_stamps(buf, 0)
+        v = [float(b) for b in buf]
+        runs = B * circ.n_theta * 2  # two sweeps were run
+        names = ["pair: load + products", "pair: sums per thread", "pair: reductions", "pair: finish + store",
+                 "2x2 at theta and variant", "patch + barriers", "(checkpoint load +) phase loop", "measurement (all of it)",
+                 "restore + barrier", "phase: head", "phase: transposition", "phase: register-bit rotations",
+                 "phase: lane-bit rotations", "phase: diagonal stage"]
+        for nm, c in zip(names, v):
+            print(f"   {nm:34s} {c / runs:9.0f} cycles per run")
     print(ev0.elapsed_time(ev1))
     sys.exit(0)
 
 args = sys.argv[1:4] or ["12", "10", "4096"]
+if os.environ.get("VQA_STAMPS_ONLY"):
+    VARIANTS = VARIANTS[:1]
 base = None
 for mask, name in VARIANTS:
     env = dict(os.environ, VQA_SECTION_CHILD="1", VQA_ABLATE=str(mask),
@@ -49,6 +64,11 @@ for mask, name in VARIANTS:
     if out.returncode != 0:
         print(name, "FAILED", out.stderr[-400:])
         sys.exit(1)
+    if mask == 0:
+        env2 = dict(env, VQA_STAMPS="1")
+        o2 = subprocess.run([sys.executable, os.path.abspath(__file__)] + args, env=env2, capture_output=True, text=True, timeout=300)
+        print("wave-0 clock stamps (100 MHz counter units x clock ratio; relative sizes matter):")
+        print("\n".join(o2.stdout.strip().split("\n")[:-1]))
     ms = float(out.stdout.strip().split()[-1])
     base = base or ms
     print(f"{name:32s} {ms:9.1f} ms   saves {100 * (base - ms) / base:5.1f} %", flush=True)

@@ -47,8 +47,21 @@ namespace vqa {
 
 #ifdef VQA_PROF
 #define VQA_ABL(a, bit) (((a).ablate >> (bit)) & 1)
+// cycle stamps of wave 0 inside the pair measurement (read with vqa_debug_stamps)
+// (summed per workgroup in LDS, added to the global totals once per sample)
+__device__ unsigned long long g_stamp[16];
+__shared__ unsigned long long s_stamp[16];
+#define VQA_STAMP0 unsigned long long st_t = clock64();
+#define VQA_STAMP(i)                                                       \
+    {                                                                      \
+        const unsigned long long st_n = clock64();                         \
+        if (threadIdx.x == 0) s_stamp[i] += st_n - st_t;                   \
+        st_t = st_n;                                                       \
+    }
 #else
 #define VQA_ABL(a, bit) 0
+#define VQA_STAMP0
+#define VQA_STAMP(i)
 #endif
 
 namespace {
@@ -66,6 +79,7 @@ struct RegArgs {
     double* out_marginal;
     double2* ckpt;     // sweep: per-workgroup checkpoint area
     unsigned* next;    // sweep: work counter (zero at launch); workgroups take samples from it
+    RunRec* recs;      // sweep: per-workgroup run records
 #ifdef VQA_PROF
     int ablate;
 #endif
@@ -111,6 +125,7 @@ struct Prog {
     const VQA_CAS SignTab* signs;
     const VQA_CAS ParamInfo* params;
     const VQA_CAS PatchRef* refs;
+    const VQA_CAS RunInfo* runs;
 };
 
 __device__ __forceinline__ Prog load_prog(const char* blob) {
@@ -128,6 +143,7 @@ __device__ __forceinline__ Prog load_prog(const char* blob) {
     p.signs = to_const<SignTab>(blob + p.H->off_signs);
     p.params = to_const<ParamInfo>(blob + p.H->off_params);
     p.refs = to_const<PatchRef>(blob + p.H->off_refs);
+    p.runs = to_const<RunInfo>(blob + p.H->off_runs);
     return p;
 }
 
@@ -328,10 +344,15 @@ __device__ __forceinline__ double xor_fetch(double v) {
 // operands so that they are in place by construction: behind the uniform
 // branches of the phase loop anything else makes the register allocator keep
 // a second copy of the state and move it back after every block.
-//   (a0, a1) <- (c a0 + s a1, c a1 - s a0) as three shears, u = tan(phi/2), s = sin(phi)
-__device__ __forceinline__ void rot_pair(double& a0, double& a1, double u, double s) {
-    asm("v_fma_f64 %0, %2, %1, %0\n\tv_fma_f64 %1, -%3, %0, %1\n\tv_fma_f64 %0, %2, %1, %0"
-        : "+v"(a0), "+v"(a1)
+//   (a0, a1) <- (c a0 + s a1, c a1 - s a0) as three shears, u = tan(phi/2), s = sin(phi),
+// for four pairs at once: the three steps of a pair depend on each other, so four
+// pairs are interleaved inside the block (blocks cannot be interleaved by the compiler)
+__device__ __forceinline__ void rot_quad(double& a0, double& a1, double& b0, double& b1, double& c0, double& c1,
+                                         double& d0, double& d1, double u, double s) {
+    asm("v_fma_f64 %0, %8, %1, %0\n\tv_fma_f64 %2, %8, %3, %2\n\tv_fma_f64 %4, %8, %5, %4\n\tv_fma_f64 %6, %8, %7, %6\n\t"
+        "v_fma_f64 %1, -%9, %0, %1\n\tv_fma_f64 %3, -%9, %2, %3\n\tv_fma_f64 %5, -%9, %4, %5\n\tv_fma_f64 %7, -%9, %6, %7\n\t"
+        "v_fma_f64 %0, %8, %1, %0\n\tv_fma_f64 %2, %8, %3, %2\n\tv_fma_f64 %4, %8, %5, %4\n\tv_fma_f64 %6, %8, %7, %6"
+        : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "+v"(c0), "+v"(c1), "+v"(d0), "+v"(d1)
         : "v"(u), "v"(s));
 }
 //   x <- c x + se p
@@ -357,13 +378,13 @@ __device__ __forceinline__ void cmul_inplace(double& ax, double& ay, double tx, 
 
 template <int J>
 __device__ __forceinline__ void apply_ureg(double2 (&amp)[kRegAmps], double u, double s) {
+    // the 8 amplitude pairs of register bit J, two pairs (re and im of each) per block
+    constexpr int lo = (1 << J) - 1;
 #pragma unroll
-    for (int r = 0; r < kRegAmps; ++r) {
-        if (!(r & (1 << J))) {
-            const int r1 = r | (1 << J);
-            rot_pair(amp[r].x, amp[r1].x, u, s);
-            rot_pair(amp[r].y, amp[r1].y, u, s);
-        }
+    for (int k = 0; k < kRegAmps / 2; k += 2) {
+        const int ra = ((k & ~lo) << 1) | (k & lo), rb = (((k + 1) & ~lo) << 1) | ((k + 1) & lo);
+        const int ra1 = ra | (1 << J), rb1 = rb | (1 << J);
+        rot_quad(amp[ra].x, amp[ra1].x, amp[ra].y, amp[ra1].y, amp[rb].x, amp[rb1].x, amp[rb].y, amp[rb1].y, u, s);
     }
 }
 
@@ -400,12 +421,17 @@ __device__ __forceinline__ void apply_ulane(double2 (&amp)[kRegAmps], double m0,
 // are then in flight together (with per-amplitude 64-bit vector addresses the
 // register budget makes the compiler reload an address between any two of them).
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// cache policy of the state-image traffic (aux operand of the buffer builtins).  The
+// non-temporal hint (2) was measured and is slower: the images are re-read many times.
+#ifndef VQA_IMAGE_AUX
+#define VQA_IMAGE_AUX 0
+#endif
 __device__ __forceinline__ void load_state(double2 (&amp)[kRegAmps], __amdgpu_buffer_rsrc_t area, unsigned image_off,
                                            unsigned nthr, unsigned tid) {
     const unsigned toff = tid * (unsigned)sizeof(double2);
 #pragma unroll
     for (int r = 0; r < kRegAmps; ++r) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(area, toff, image_off + r * nthr * (unsigned)sizeof(double2), 0);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(area, toff, image_off + r * nthr * (unsigned)sizeof(double2), VQA_IMAGE_AUX);
         amp[r] = *(const double2*)&v;
     }
 }
@@ -416,7 +442,7 @@ __device__ __forceinline__ void store_state(const double2 (&amp)[kRegAmps], __am
     for (int r = 0; r < kRegAmps; ++r) {
         const double2 d = amp[r];
         __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4*)&d, area, toff,
-                                               image_off + r * nthr * (unsigned)sizeof(double2), 0);
+                                               image_off + r * nthr * (unsigned)sizeof(double2), VQA_IMAGE_AUX);
     }
 }
 
@@ -555,6 +581,7 @@ __device__ __forceinline__ void run_phases(double2 (&amp)[kRegAmps], const Prog&
                                            bool diag_only_first, bool ckpt) {
     const VQA_CAS PhaseOp* ph = pp.phases;
     int first_mask = diag_only_first ? (PH_DIAG | PH_END) : -1;
+    VQA_STAMP0
     for (int p = p0;; ++p) {
 #ifdef VQA_PROF
         const int flags = ph[p].flags & first_mask & cx.flag_mask;
@@ -563,7 +590,9 @@ __device__ __forceinline__ void run_phases(double2 (&amp)[kRegAmps], const Prog&
 #endif
         first_mask = -1;
         if (flags & PH_END) break;
+        VQA_STAMP(9)
         if (flags & PH_XPOSE) do_xpose(amp, pp, cx, ph[p].xdesc);
+        VQA_STAMP(10)
         // rotations: the table entry of the next slot is fetched while the current one runs
         double2 cs = cx.mat[ph[p].ent[0]], csn;
 #define VQA_REG_SLOT(J)                                           \
@@ -572,6 +601,7 @@ __device__ __forceinline__ void run_phases(double2 (&amp)[kRegAmps], const Prog&
         cs = csn;
         VQA_REG_SLOT(0) VQA_REG_SLOT(1) VQA_REG_SLOT(2) VQA_REG_SLOT(3)
 #undef VQA_REG_SLOT
+        VQA_STAMP(11)
         // (with one state per workgroup the two scaled forms are separate optional
         // blocks, not an if / else: each block then updates the amplitudes in place)
 #define VQA_LANE_SLOT(LB)                                                  \
@@ -587,32 +617,87 @@ __device__ __forceinline__ void run_phases(double2 (&amp)[kRegAmps], const Prog&
         cs = csn;
         VQA_LANE_SLOT(0) VQA_LANE_SLOT(1) VQA_LANE_SLOT(2) VQA_LANE_SLOT(3) VQA_LANE_SLOT(4) VQA_LANE_SLOT(5)
 #undef VQA_LANE_SLOT
+        VQA_STAMP(12)
         if (flags & PH_DIAG) {
             const int did = ph[p].ddesc;
             if (ckpt) store_state(amp, cx.area, (unsigned)did * cx.image_bytes, cx.nthr, cx.tid);
             do_diag(amp, pp, cx, did);
+        }
+        VQA_STAMP(13)
+    }
+}
+
+// Sum of v over the 64 lanes of a wave (every lane gets it): DPP inside the rows
+// of 16 lanes, then the four row sums through scalar registers.
+template <int CTRL>
+__device__ __forceinline__ double row_step(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+    return v + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum(double v) {
+    v = row_step<0xB1>(v);    // quad_perm [1,0,3,2]
+    v = row_step<0x4E>(v);    // quad_perm [2,3,0,1]
+    v = row_step<0x141>(v);   // row_half_mirror
+    v = row_step<0x140>(v);   // row_mirror
+    double s = 0.0;
+#pragma unroll
+    for (int row = 0; row < 4; ++row) {
+        const int lo = __builtin_amdgcn_readlane(__double2loint(v), row * 16);
+        const int hi = __builtin_amdgcn_readlane(__double2hiint(v), row * 16);
+        s += __hiloint2double(hi, lo);
+    }
+    return s;
+}
+
+// Sums NV per-thread values over the threads of a state.  T >= 6: a state is a whole
+// workgroup; wave sums meet in LDS (red, two alternating halves so that one barrier
+// per call is enough as long as calls are separated by another barrier).
+template <int NV>
+__device__ __forceinline__ void state_sum(double (&v)[NV], const Ctx& cx, double* red, unsigned& parity) {
+    if (cx.T < 6) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+            for (int i = 0; i < cx.T; ++i) v[k] += __shfl_xor(v[k], 1 << i, 64);
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = wave_sum(v[k]);
+    if (cx.T > 6) {
+        const int wave = cx.tid >> 6, nwave = cx.nthr >> 6;
+        double* buf = red + (parity & 1u) * 32;
+        parity ^= 1u;
+        if (cx.lane == 0) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) buf[k * 8 + wave] = v[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            v[k] = 0.0;
+            for (int w = 0; w < nwave; ++w) v[k] += buf[k * 8 + w];
         }
     }
 }
 
 // Z-basis observables and the low-bit marginal of the state held in amp, which
 // may carry any common factor: every value is divided by the squared norm.
-// Instance index e, written by the thread with t == 0.
+// Instance index e, written by the thread with t == 0 (and kept in basev when
+// given).  Returns the squared norm of the state as held.
 __device__ __forceinline__ double measure(const double2 (&amp)[kRegAmps], const RegArgs& a, const Ctx& cx, unsigned kt,
-                                          const unsigned (&krb)[kRegBits], double* red, int64_t e, bool live,
-                                          bool valid) {
+                                          const unsigned (&krb)[kRegBits], double* red, unsigned& parity, int64_t e,
+                                          bool live, bool valid, double* basev) {
     const double nanv = __longlong_as_double(0x7ff8000000000000LL);
     const int nq = a.obs.n_obs + (a.n_marg_bits > 0 ? (1 << a.n_marg_bits) : 0);
-    const int wave = cx.tid >> 6, nwave = cx.nthr >> 6;
     double pr[kRegAmps];
 #pragma unroll
     for (int r = 0; r < kRegAmps; ++r) pr[r] = amp[r].x * amp[r].x + amp[r].y * amp[r].y;
     double inv_norm = 1.0;
     for (int q = 0; q < nq; ++q) {
-        double acc = 0.0, nrm = 0.0;
+        double v[2] = { 0.0, 0.0 };   // the quantity; with the first one the norm
         if (q == 0) {
 #pragma unroll
-            for (int r = 0; r < kRegAmps; ++r) nrm += pr[r];
+            for (int r = 0; r < kRegAmps; ++r) v[1] += pr[r];
         }
         if (q < a.obs.n_obs) {
             for (int tm = a.obs.off[q]; tm < a.obs.off[q + 1]; ++tm) {
@@ -627,7 +712,7 @@ __device__ __forceinline__ double measure(const double2 (&amp)[kRegAmps], const 
                         if (r & (1 << j)) rp += __popc(krb[j] & z);
                     part += flip_if(pr[r], rp & 1u);
                 }
-                acc += a.obs.coef[tm] * part;
+                v[0] += a.obs.coef[tm] * part;
             }
         } else {
             const unsigned m = (unsigned)(q - a.obs.n_obs), M1 = (1u << a.n_marg_bits) - 1;
@@ -637,36 +722,25 @@ __device__ __forceinline__ double measure(const double2 (&amp)[kRegAmps], const 
 #pragma unroll
                 for (int j = 0; j < kRegBits; ++j)
                     if (r & (1 << j)) k |= krb[j];
-                acc += ((k & M1) == m) ? pr[r] : 0.0;
+                v[0] += ((k & M1) == m) ? pr[r] : 0.0;
             }
         }
-        // sum over the threads of the state; the first quantity carries the norm along
-        const int lb = cx.T < 6 ? cx.T : 6;
-        for (int i = 0; i < lb; ++i) acc += __shfl_xor(acc, 1 << i, 64);
-        if (q == 0)
-            for (int i = 0; i < lb; ++i) nrm += __shfl_xor(nrm, 1 << i, 64);
-        if (cx.T > 6) {
-            __syncthreads();
-            if (cx.lane == 0) {
-                red[wave] = acc;
-                if (q == 0) red[16 + wave] = nrm;
-            }
-            __syncthreads();
-            acc = 0.0;
-            for (int w = 0; w < nwave; ++w) acc += red[w];
-            if (q == 0) {
-                nrm = 0.0;
-                for (int w = 0; w < nwave; ++w) nrm += red[16 + w];
-            }
+        if (q == 0) {
+            state_sum<2>(v, cx, red, parity);
+            inv_norm = 1.0 / v[1];
+        } else {
+            double w[1] = { v[0] };
+            state_sum<1>(w, cx, red, parity);
+            v[0] = w[0];
         }
-        if (q == 0) inv_norm = 1.0 / nrm;
-        acc *= inv_norm;
+        const double val = v[0] * inv_norm;
         if (cx.t == 0 && live) {
-            if (q < a.obs.n_obs) a.out_expect[e * a.obs.n_obs + q] = valid ? acc : nanv;
-            else a.out_marginal[(e << a.n_marg_bits) + (q - a.obs.n_obs)] = valid ? acc : nanv;
+            if (q < a.obs.n_obs) a.out_expect[e * a.obs.n_obs + q] = valid ? val : nanv;
+            else a.out_marginal[(e << a.n_marg_bits) + (q - a.obs.n_obs)] = valid ? val : nanv;
+            if (basev) basev[q] = val;
         }
     }
-    return 1.0 / inv_norm;   // squared norm of the state as held
+    return 1.0 / inv_norm;
 }
 
 // Both shifted values of one parameter from ONE extra state.  With psi the
@@ -674,25 +748,32 @@ __device__ __forceinline__ double measure(const double2 (&amp)[kRegAmps], const 
 // parameter's generator inserted in front of its rotation, the states at
 // +-kappa are cos(kappa/2) psi +- i sin(kappa/2) phi, so for a diagonal O
 //   <O>(+-) = cos^2 <O>_psi + sin^2 <O>_phi -+ 2 cos sin Im <psi|O|phi>.
-// amp holds phi (any scale), image psi_image of the area the stored psi (scale^2 = psi_norm), rho the
-// ratio of the unit factors the engine left out of the two runs; e0 = instance
-// index of the unshifted evaluation, e1 that of +kappa (-kappa is e1 + 1).
-__device__ __forceinline__ void measure_pair(double2 (&amp)[kRegAmps], unsigned psi_image, double psi_norm, cplx rho,
-                                             double ck, double sk, const RegArgs& a, const Ctx& cx, unsigned kt,
-                                             const unsigned (&krb)[kRegBits], double* red, int64_t e0, int64_t e1,
-                                             bool valid) {
+// amp holds phi (any scale), image psi_image of the area the stored psi (scale^2 =
+// psi_norm), basev the unshifted values; rec (LDS) gives rho = the ratio of the
+// unit factors the engine left out of the two runs and (cos, sin)(kappa/2);
+// e1 = instance index of +kappa (-kappa is e1 + 1).
+__device__ __forceinline__ void measure_pair(double2 (&amp)[kRegAmps], unsigned psi_image, double psi_norm,
+                                             const double2* rec, const double* basev, const RegArgs& a, const Ctx& cx,
+                                             unsigned kt, const unsigned (&krb)[kRegBits], double* red,
+                                             unsigned& parity, int64_t e1, bool valid) {
     const double nanv = __longlong_as_double(0x7ff8000000000000LL);
     const int nq = a.obs.n_obs + (a.n_marg_bits > 0 ? (1 << a.n_marg_bits) : 0);
-    const int wave = cx.tid >> 6, nwave = cx.nthr >> 6;
+    const unsigned toff = cx.tid * (unsigned)sizeof(double2), rstep = cx.nthr * (unsigned)sizeof(double2);
     double pr[kRegAmps];
-    // amp <- conj(psi) phi, pr <- |phi|^2
+    // amp <- conj(psi) phi, pr <- |phi|^2; the loads of psi run eight ahead
+    u32x4 pv[kRegAmps / 2];
+#pragma unroll
+    for (int r = 0; r < kRegAmps / 2; ++r)
+        pv[r] = __builtin_amdgcn_raw_buffer_load_b128(cx.area, toff, psi_image + r * rstep, VQA_IMAGE_AUX);
+#pragma unroll
+    for (int r = 0; r < kRegAmps; ++r) pr[r] = amp[r].x * amp[r].x + amp[r].y * amp[r].y;
 #pragma unroll
     for (int r = 0; r < kRegAmps; ++r) {
-        const u32x4 pv = __builtin_amdgcn_raw_buffer_load_b128(cx.area, cx.tid * (unsigned)sizeof(double2),
-                                                               psi_image + r * cx.nthr * (unsigned)sizeof(double2), 0);
-        const double2 ps = VQA_ABL(a, 10) ? make_double2(1.0, 0.5) : *(const double2*)&pv;
+        const u32x4 cur = pv[r & 7];
+        if (r + 8 < kRegAmps)
+            pv[r & 7] = __builtin_amdgcn_raw_buffer_load_b128(cx.area, toff, psi_image + (r + 8) * rstep, VQA_IMAGE_AUX);
+        const double2 ps = VQA_ABL(a, 10) ? make_double2(1.0, 0.5) : *(const double2*)&cur;
         const double2 ph = amp[r];
-        pr[r] = ph.x * ph.x + ph.y * ph.y;
         amp[r] = make_double2(ps.x * ph.x + ps.y * ph.y, ps.x * ph.y - ps.y * ph.x);
     }
     double inv_norm = 1.0, inv_cross = 1.0;
@@ -734,41 +815,24 @@ __device__ __forceinline__ void measure_pair(double2 (&amp)[kRegAmps], unsigned 
                 v[2] += in ? amp[r].y : 0.0;
             }
         }
-        const int lb = VQA_ABL(a, 11) ? 0 : (cx.T < 6 ? cx.T : 6);
-        const int nv = q == 0 ? 4 : 3;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (k < nv)
-                for (int i = 0; i < lb; ++i) v[k] += __shfl_xor(v[k], 1 << i, 64);
-        if (cx.T > 6 && !VQA_ABL(a, 11)) {
-            __syncthreads();
-            if (cx.lane == 0) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) red[k * 8 + wave] = v[k];
-            }
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (k < nv) {
-                    v[k] = 0.0;
-                    for (int w = 0; w < nwave; ++w) v[k] += red[k * 8 + w];
-                }
-            }
-        }
         if (q == 0) {
+            state_sum<4>(v, cx, red, parity);
             inv_norm = 1.0 / v[3];
             inv_cross = rsqrt(v[3] * psi_norm);
+        } else {
+            double w[3] = { v[0], v[1], v[2] };
+            state_sum<3>(w, cx, red, parity);
+            v[0] = w[0]; v[1] = w[1]; v[2] = w[2];
         }
         if (cx.t == 0) {
             const bool is_obs = q < a.obs.n_obs;
-            const size_t o0 = is_obs ? (size_t)e0 * a.obs.n_obs + q : ((size_t)e0 << a.n_marg_bits) + (q - a.obs.n_obs);
             const size_t o1 = is_obs ? (size_t)e1 * a.obs.n_obs + q : ((size_t)e1 << a.n_marg_bits) + (q - a.obs.n_obs);
             const size_t step = is_obs ? (size_t)a.obs.n_obs : ((size_t)1 << a.n_marg_bits);
             double* out = is_obs ? a.out_expect : a.out_marginal;
-            const double base = out[o0];
+            const double2 rho = rec[3], cs = rec[4];
             const double im = (rho.x * v[2] + rho.y * v[1]) * inv_cross;   // Im(rho * sum)
-            const double mid = ck * ck * base + sk * sk * v[0] * inv_norm;
-            const double dev = 2.0 * ck * sk * im;
+            const double mid = cs.x * cs.x * basev[q] + cs.y * cs.y * v[0] * inv_norm;
+            const double dev = 2.0 * cs.x * cs.y * im;
             out[o1] = valid ? mid - dev : nanv;
             out[o1 + step] = valid ? mid + dev : nanv;
         }
@@ -842,6 +906,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : VQA_WAVES) void k_reg_eva
     unsigned kt, krb[kRegBits];
     thread_constants<BLOCK>(pp, smask, T, t, tid, kt, krb);
 
+    unsigned parity = 0;
     for (int64_t e0 = (int64_t)blockIdx.x * S; e0 < a.E; e0 += (int64_t)gridDim.x * S) {
         const int64_t e = e0 + sl;
         const bool live = e < a.E;
@@ -860,7 +925,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : VQA_WAVES) void k_reg_eva
         for (int r = 0; r < kRegAmps; ++r) amp[r] = make_double2(0.0, 0.0);
         if (t == 0) amp[0].x = 1.0;
         run_phases<SCALED>(amp, pp, cx, 0, false, false);
-        measure(amp, a, cx, kt, krb, red, e, live, valid);
+        measure(amp, a, cx, kt, krb, red, parity, e, live, valid, nullptr);
     }
 }
 
@@ -869,27 +934,83 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : VQA_WAVES) void k_reg_eva
 // j * (2P+1) + k.  One state per workgroup (BLOCK = 2^T >= 64 threads).
 // Workgroups draw samples from a shared counter until it passes a.E, so the
 // launch may hold more workgroups than are resident at once.
+//
+// Per sample: the tables of the unshifted circuit; one record per run of the
+// sweep (what to patch, where to resume, how to measure), worked out by all
+// threads side by side and parked in global memory; the unshifted run, which
+// leaves a checkpoint in front of every diagonal stage and the final state;
+// then the runs one after the other, each: thread 0 undoes the previous patch
+// and applies this run's, everybody resumes from the checkpoint and measures.
+// The record of the next run is fetched while the current one computes.
+template <int BLOCK>
+__device__ __forceinline__ void make_run_record(const RegArgs& a, const Prog& pp, int r, const double* row, int NU, int N1,
+                                                RunRec* out) {
+    const int i = pp.runs[r].param, variant = pp.runs[r].variant;
+    const int ref_count = pp.params[i].ref_count;
+    const int kind = ref_count > 0 ? pp.refs[pp.params[i].ref_begin].kind : -1;
+    const int index = ref_count > 0 ? pp.refs[pp.params[i].ref_begin].index : 0;
+    const double coef_sum = ref_count > 0 ? pp.refs[pp.params[i].ref_begin].coef_sum : 0.0;
+    const double shift = variant == 2 ? -a.spec.shift : a.spec.shift;
+    double2 m = make_double2(0, 0);
+    cplx fb = { 1, 0 }, fa = { 1, 0 }, rho = { 1, 0 };
+    int id_m = -1, id_b = -1, id_a = -1;
+    if (kind == 0) {
+        // the fused 2x2 at theta, then with the generator inserted (variant 0) or the angle shifted
+        double2 mv[2];
+        cplx A[2], G[2], gp[2];
+#pragma unroll 1
+        for (int v = 0; v < 2; ++v)
+            compute_uentry<true>(pp, index, a.theta, row, (v == 1 && variant != 0) ? i : -1, shift,
+                                 (v == 1 && variant == 0) ? i : -1, mv[v], A[v], G[v], gp[v]);
+        m = mv[1];
+        fb = cmul(cconj(G[0]), G[1]);
+        fa = cmul(cconj(A[0]), A[1]);
+        rho = cmul(gp[1], cconj(gp[0]));
+        id_m = index;
+        if (pp.uent[index].d_before >= 0) id_b = NU + pp.uent[index].d_before;
+        if (pp.uent[index].d_after >= 0) id_a = NU + pp.uent[index].d_after;
+    } else if (kind > 0) {
+        double sn, c;
+        sincos(0.5 * coef_sum * shift, &sn, &c);
+        fb = { c, sn };
+        id_b = kind == 1 ? NU + index : NU + N1 + index;
+    }
+    double sk, ck;
+    sincos(0.5 * coef_sum * a.spec.shift, &sk, &ck);
+    RunRec rec;
+    rec.m[0] = m.x; rec.m[1] = m.y;
+    rec.fb[0] = fb.x; rec.fb[1] = fb.y;
+    rec.fa[0] = fa.x; rec.fa[1] = fa.y;
+    rec.rho[0] = rho.x; rec.rho[1] = rho.y;
+    rec.cs[0] = ck; rec.cs[1] = sk;
+    rec.ids[0] = id_m; rec.ids[1] = id_b; rec.ids[2] = id_a; rec.ids[3] = 0;
+    rec.out[0] = variant == 0 ? 1 : 0;
+    rec.out[1] = 1 + 2 * i + (variant == 2 ? 1 : 0);
+    rec.out[2] = pp.params[i].resume_diag;
+    rec.out[3] = pp.params[i].resume_pc;
+    rec.pad[0] = rec.pad[1] = 0.0;
+    *out = rec;
+}
+
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : VQA_WAVES) void k_reg_psr(RegArgs a) {
     extern __shared__ double2 smem[];
     const Prog pp = load_prog(a.prog);
     const int n = pp.H->n, T = pp.H->T;
     const int NU = pp.H->n_uent, N1 = pp.H->n_d1, N2 = pp.H->n_d2, ND = pp.H->n_ddesc;
-    const int P = pp.H->n_params;
+    const int P = pp.H->n_params, NR = pp.H->n_runs;
     const int tid = threadIdx.x;
     const int t = tid;
 
     double2* tabs = smem;
     double2* xbuf = tabs + (size_t)(NU + N1 + N2);
     double* red = (double*)(xbuf + (pp.H->has_xpose ? ((size_t)1 << (n - 1)) : 0));
-    double2* pz = (double2*)(red + 64);                   // 12 entries: 2x2 data at theta and at two variants
-    unsigned short* smask = (unsigned short*)(pz + 16);
-    double2* mat = tabs;
-    double2* ph1 = tabs + NU;
-    double2* ph2 = ph1 + N1;
+    double2* pz = (double2*)(red + 64);                   // the current run's record (8 entries)
+    double* basev = (double*)(pz + 16);                   // the unshifted values (80 entries)
+    unsigned short* smask = (unsigned short*)(basev + 80);
 
     Ctx cx;
-    cx.mat = mat; cx.ph1 = ph1; cx.ph2 = ph2;
+    cx.mat = tabs; cx.ph1 = tabs + NU; cx.ph2 = tabs + NU + N1;
     cx.xbuf = (char*)xbuf;
     cx.smask = smask;
     cx.T = T; cx.t = t; cx.tid = tid; cx.lane = tid & 63; cx.nthr = BLOCK;
@@ -906,118 +1027,107 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : VQA_WAVES) void k_reg_psr
     cx.image_bytes = 16u << n;
     cx.area = __builtin_amdgcn_make_buffer_rsrc((void*)(a.ckpt + (size_t)blockIdx.x * ((size_t)(ND + 1) << n)), 0,
                                                 (ND + 1) * cx.image_bytes, 0x00020000);
+    const double2* recs = (const double2*)(a.recs + (size_t)blockIdx.x * NR);
     const int K = 2 * P + 1;
-    const double shift = a.spec.shift;
+    unsigned parity = 0;
 
     __shared__ unsigned s_next;
+#ifdef VQA_PROF
+    if (tid < 16) s_stamp[tid] = 0;
+#endif
     for (;;) {
         __syncthreads();
         if (tid == 0) s_next = atomicAdd(a.next, 1u);
         __syncthreads();
         const int64_t j = s_next;
+#ifdef VQA_PROF
+        if (tid < 16) {
+            if (s_stamp[tid]) atomicAdd(&g_stamp[tid], s_stamp[tid]);
+            s_stamp[tid] = 0;
+        }
+#endif
         if (j >= a.E) break;
         int b = a.spec.sel ? a.spec.sel[j] : (int)j;
         const bool valid = a.spec.B == 0 || (unsigned)b < (unsigned)a.spec.B;
         if (!valid) b = 0;
         const double* row = a.input + (size_t)b * a.n_input;
+        VQA_STAMP0
         __syncthreads();
         prep_tables<true, true>(a, pp, tabs, j, 1, NU, N1, N2, tid, BLOCK);
-        __syncthreads();
+        for (int r = tid; r < NR; r += BLOCK)
+            make_run_record<BLOCK>(a, pp, r, row, NU, N1, a.recs + (size_t)blockIdx.x * NR + r);
+        __threadfence_block();
+        VQA_STAMP(0)
 
-        double2 amp[kRegAmps];
-#pragma unroll
-        for (int r = 0; r < kRegAmps; ++r) amp[r] = make_double2(0.0, 0.0);
-        if (t == 0) amp[0].x = 1.0;
-        run_phases<true>(amp, pp, cx, 0, false, true);
-        // the unshifted final state, for the parameters evaluated as a pair
-        store_state(amp, cx.area, (unsigned)ND * cx.image_bytes, BLOCK, tid);
-        const double psi_norm = measure(amp, a, cx, kt, krb, red, j * K, true, valid);
-
-        for (int i = 0; i < P; ++i) {
-            const int ref_count = pp.params[i].ref_count;
-            const int rdiag = pp.params[i].resume_diag, rpc = pp.params[i].resume_pc;
-            // the one table entry the parameter enters (sweeps are only launched
-            // for programs where every parameter enters at most one)
-            const int kind = ref_count > 0 ? pp.refs[pp.params[i].ref_begin].kind : -1;
-            const int index = ref_count > 0 ? pp.refs[pp.params[i].ref_begin].index : 0;
-            const double coef_sum = ref_count > 0 ? pp.refs[pp.params[i].ref_begin].coef_sum : 0.0;
-            // pair evaluation: the parameter drives one rotation of a fused 2x2 whose
-            // trailing phase goes into a later diagonal stage (so that both runs end in
-            // the same frame); otherwise the two shifted circuits are run one by one
-            const bool pair = kind == 0 && coef_sum != 0.0 && pp.uent[index].d_after >= 0 && !VQA_ABL(a, 9);
-            const int nrun = pair ? 1 : 2;
-            // lanes 0..2 work out the fused 2x2 at theta and at the variants
+        // run -1 is the unshifted circuit; thread 0 keeps what the current patch replaced
+        double psi_norm = 1.0;
+        int old_m = -1, old_b = -1, old_a = -1;
+        double2 sav_m = make_double2(0, 0), sav_b = sav_m, sav_a = sav_m, nx = sav_m;
+        for (int r = -1; r <= NR; ++r) {
+            VQA_STAMP0
+            __syncthreads();   // the previous run is over (tables free); its successor's record is in pz
+            int id_m = -1, id_b = -1, id_a = -1, mode = 0, kout = 0, rdiag = -1, rpc = 0;
+            if (r >= 0 && r < NR) {
+                const int4 ids = *(const int4*)&pz[5], o = *(const int4*)&pz[6];
+                id_m = __builtin_amdgcn_readfirstlane(ids.x);
+                id_b = __builtin_amdgcn_readfirstlane(ids.y);
+                id_a = __builtin_amdgcn_readfirstlane(ids.z);
+                mode = __builtin_amdgcn_readfirstlane(o.x);
+                kout = __builtin_amdgcn_readfirstlane(o.y);
+                rdiag = __builtin_amdgcn_readfirstlane(o.z);
+                rpc = __builtin_amdgcn_readfirstlane(o.w);
+            }
+            if (tid == 0 && !VQA_ABL(a, 7)) {
+                if (old_a >= 0) tabs[old_a] = sav_a;
+                if (old_b >= 0) tabs[old_b] = sav_b;
+                if (old_m >= 0) tabs[old_m] = sav_m;
+                if (id_m >= 0) { sav_m = tabs[id_m]; tabs[id_m] = pz[0]; }
+                if (id_b >= 0) {
+                    sav_b = tabs[id_b];
+                    const double2 f = pz[1];
+                    const cplx q = cmul({ sav_b.x, sav_b.y }, { f.x, f.y });
+                    tabs[id_b] = make_double2(q.x, q.y);
+                }
+                if (id_a >= 0) {
+                    sav_a = tabs[id_a];
+                    const double2 f = pz[2];
+                    const cplx q = cmul({ sav_a.x, sav_a.y }, { f.x, f.y });
+                    tabs[id_a] = make_double2(q.x, q.y);
+                }
+            }
+            old_m = id_m; old_b = id_b; old_a = id_a;
+            if (r == NR) break;   // (the last pass only undoes the last patch)
             __syncthreads();
-            if (kind == 0 && tid < 1 + (pair ? 1 : 2) && !VQA_ABL(a, 5)) {
-                double2 cs;
-                cplx A, G, gp;
-                compute_uentry<true>(pp, index, a.theta, row, (tid == 0 || pair) ? -1 : i, tid == 1 ? shift : -shift,
-                                     (pair && tid == 1) ? i : -1, cs, A, G, gp);
-                pz[tid * 4 + 0] = cs;
-                pz[tid * 4 + 1] = make_double2(A.x, A.y);
-                pz[tid * 4 + 2] = make_double2(G.x, G.y);
-                pz[tid * 4 + 3] = make_double2(gp.x, gp.y);
-            }
-            for (int sgn = 0; sgn < nrun; ++sgn) {
-                // thread 0 patches the entry (old values stay in its registers)
-                double2 old_mat = make_double2(0, 0), old_a = old_mat, old_b = old_mat;
-                __syncthreads();
-                if (tid == 0 && kind == 0 && !VQA_ABL(a, 7)) {
-                    const int d_before = pp.uent[index].d_before, d_after = pp.uent[index].d_after;
-                    const double2 A0 = pz[1], G0 = pz[2], A1 = pz[(1 + sgn) * 4 + 1], G1 = pz[(1 + sgn) * 4 + 2];
-                    old_mat = mat[index];
-                    mat[index] = pz[(1 + sgn) * 4];
-                    if (d_before >= 0) {
-                        old_a = ph1[d_before];
-                        const cplx q = cmul(cmul({ old_a.x, old_a.y }, { G0.x, -G0.y }), { G1.x, G1.y });
-                        ph1[d_before] = make_double2(q.x, q.y);
-                    }
-                    if (d_after >= 0) {
-                        old_b = ph1[d_after];
-                        const cplx q = cmul(cmul({ old_b.x, old_b.y }, { A0.x, -A0.y }), { A1.x, A1.y });
-                        ph1[d_after] = make_double2(q.x, q.y);
-                    }
-                } else if (tid == 0 && kind > 0) {
-                    double2* slot = kind == 1 ? &ph1[index] : &ph2[index];
-                    old_a = *slot;
-                    double sn, c;
-                    sincos(0.5 * coef_sum * (sgn ? -shift : shift), &sn, &c);
-                    const cplx q = cmul({ old_a.x, old_a.y }, { c, sn });
-                    *slot = make_double2(q.x, q.y);
-                }
-                __syncthreads();
-                int pc0 = 0;
-                if (rdiag >= 0) {
-                    if (!VQA_ABL(a, 6)) load_state(amp, cx.area, (unsigned)rdiag * cx.image_bytes, BLOCK, tid);
-                    pc0 = rpc;
-                } else {
+            VQA_STAMP(1)
+            // the next run's record travels while this run computes
+            if (r + 1 < NR && cx.lane < 8) nx = recs[(size_t)(r + 1) * 8 + cx.lane];
+
+            double2 amp[kRegAmps];
+            int pc0 = 0;
+            if (rdiag >= 0) {
+                if (!VQA_ABL(a, 6)) load_state(amp, cx.area, (unsigned)rdiag * cx.image_bytes, BLOCK, tid);
+                pc0 = rpc;
+            } else {
 #pragma unroll
-                    for (int r = 0; r < kRegAmps; ++r) amp[r] = make_double2(0.0, 0.0);
-                    if (t == 0) amp[0].x = 1.0;
-                }
-                if (!VQA_ABL(a, 8)) run_phases<true>(amp, pp, cx, pc0, rdiag >= 0, false);
-                if (!VQA_ABL(a, 4)) {
-                    if (pair) {
-                        const double2 g0 = pz[3], g1 = pz[7];
-                        const cplx rho = cmul({ g1.x, g1.y }, { g0.x, -g0.y });
-                        double sk, ck;
-                        sincos(0.5 * coef_sum * shift, &sk, &ck);
-                        measure_pair(amp, (unsigned)ND * cx.image_bytes, psi_norm, rho, ck, sk, a, cx, kt, krb, red, j * K, j * K + 1 + 2 * i,
-                                     valid);
-                    } else {
-                        measure(amp, a, cx, kt, krb, red, j * K + 1 + 2 * i + sgn, true, valid);
-                    }
-                }
-                __syncthreads();
-                if (tid == 0 && kind == 0 && !VQA_ABL(a, 7)) {
-                    const int d_before = pp.uent[index].d_before, d_after = pp.uent[index].d_after;
-                    if (d_after >= 0) ph1[d_after] = old_b;
-                    if (d_before >= 0) ph1[d_before] = old_a;
-                    mat[index] = old_mat;
-                } else if (tid == 0 && kind > 0) {
-                    *(kind == 1 ? &ph1[index] : &ph2[index]) = old_a;
+                for (int q = 0; q < kRegAmps; ++q) amp[q] = make_double2(0.0, 0.0);
+                if (t == 0) amp[0].x = 1.0;
+            }
+            if (!VQA_ABL(a, 8)) run_phases<true>(amp, pp, cx, pc0, rdiag >= 0, r < 0);
+            VQA_STAMP(2)
+            if (r < 0) store_state(amp, cx.area, (unsigned)ND * cx.image_bytes, BLOCK, tid);
+            if (!VQA_ABL(a, 4)) {
+                if (mode == 1) {
+                    measure_pair(amp, (unsigned)ND * cx.image_bytes, psi_norm, pz, basev, a, cx, kt, krb, red, parity,
+                                 j * K + kout, valid);
+                } else {
+                    const double nrm = measure(amp, a, cx, kt, krb, red, parity, j * K + kout, true, valid,
+                                               r < 0 ? basev : nullptr);
+                    if (r < 0) psi_norm = nrm;
                 }
             }
+            VQA_STAMP(3)
+            // hand the fetched record over (read by everybody after the barrier on top)
+            if (tid < 8 && r + 1 < NR) pz[tid] = nx;
         }
     }
 }
@@ -1047,6 +1157,7 @@ static RegArgs make_args(const EvalCall& call, const void* d_prog) {
     a.out_marginal = call.d_out_marginal;
     a.ckpt = nullptr;
     a.next = nullptr;
+    a.recs = nullptr;
 #ifdef VQA_PROF
     const char* abl = getenv("VQA_ABLATE");
     a.ablate = abl ? atoi(abl) : 0;
@@ -1100,11 +1211,13 @@ int reg_engine_sweep(const EvalCall& call, const void* d_prog, const RegProgram&
     const int per_cu = std::max<int>(1, std::min<int>(8, (int)((160 * 1024) / std::max<size_t>(P.lds_bytes_psr, 1))));
     const int grid = (int)std::min<int64_t>(n_samples, (int64_t)256 * per_cu);
     const size_t ck_bytes = (size_t)grid * (P.hdr.n_ddesc + 1) * ((size_t)16 << P.hdr.n);
+    const size_t rec_bytes = (size_t)grid * std::max(P.hdr.n_runs, 1) * sizeof(RunRec);
     void* ws = nullptr;
-    rc = workspace_get(call.device, ck_bytes + 256, &ws);
+    rc = workspace_get(call.device, 256 + ck_bytes + rec_bytes, &ws);
     if (rc) return rc;
     a.next = (unsigned*)ws;
     a.ckpt = (double2*)((char*)ws + 256);
+    a.recs = (RunRec*)((char*)ws + 256 + ck_bytes);
     VQA_HIP(hipMemsetAsync(a.next, 0, 256, call.stream));
     const void* fn = P.hdr.block == 64 ? (const void*)k_reg_psr<64>
                    : P.hdr.block == 128 ? (const void*)k_reg_psr<128>
@@ -1120,5 +1233,17 @@ int reg_engine_sweep(const EvalCall& call, const void* d_prog, const RegProgram&
     VQA_HIP(hipGetLastError());
     return VQA_OK;
 }
+
+#ifdef VQA_PROF
+extern "C" int vqa_debug_stamps(unsigned long long* out, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = { 0 };
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 }  // namespace vqa

@@ -507,6 +507,22 @@ bool reg_compile(int n, int n_theta, const std::vector<vqa_op>& gate_list, RegPr
         }
     }
 
+    // runs of a sweep: one per parameter where both shifts can come from one run
+    // (the parameter drives exactly one rotation of a fused 2x2 whose trailing phase
+    // goes into a later diagonal stage, so that both runs end in the same frame),
+    // otherwise one per shift
+    for (int i = 0; i < n_theta; ++i) {
+        const ParamInfo& pi = P.params[i];
+        bool pair = false;
+        if (pi.ref_count == 1) {
+            const PatchRef& ref = P.refs[pi.ref_begin];
+            pair = ref.kind == 0 && ref.coef_sum != 0.0 && P.uent[ref.index].d_after >= 0;
+        }
+        if (pair) P.runs.push_back(RunInfo{ i, 0 });
+        else { P.runs.push_back(RunInfo{ i, 1 }); P.runs.push_back(RunInfo{ i, 2 }); }
+    }
+    H.n_runs = (int)P.runs.size();
+
     H.n_uent = (int)P.uent.size();
     H.n_d1 = (int)P.d1.size();
     H.n_d2 = (int)P.d2.size();
@@ -526,7 +542,7 @@ bool reg_compile(int n, int n_theta, const std::vector<vqa_op>& gate_list, RegPr
     const size_t xbuf = H.has_xpose ? ((size_t)8 << n) : 0;  // half of the state at a time
     const size_t fixed = 64 * sizeof(double) + (((size_t)H.n_sign * H.block * 2 + 15) & ~(size_t)15);
     P.lds_bytes = (size_t)H.S * tab1 + xbuf + fixed;
-    P.lds_bytes_psr = tab1 + xbuf + fixed + 16 * 16;
+    P.lds_bytes_psr = tab1 + xbuf + fixed + 16 * 16 + 80 * sizeof(double);  // + run record, unshifted values
     if (P.lds_bytes > 160 * 1024) { *why = "per-evaluation tables do not fit LDS"; return false; }
 
     // ---- device blob ----
@@ -544,6 +560,7 @@ bool reg_compile(int n, int n_theta, const std::vector<vqa_op>& gate_list, RegPr
     H.off_params = place(P.blob, P.params);
     H.off_refs = place(P.blob, P.refs);
     H.off_phases = place(P.blob, P.phases);
+    H.off_runs = place(P.blob, P.runs);
     while (P.blob.size() % 16) P.blob.push_back(0);
     H.total_bytes = (int64_t)P.blob.size();
     memcpy(P.blob.data(), &H, sizeof(H));

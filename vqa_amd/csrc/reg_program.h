@@ -143,19 +143,39 @@ struct ParamInfo {
     int32_t resume_pc;             // phase to resume at, starting with its diagonal stage (0 when restarting)
 };
 
+// One run of a parameter-shift sweep besides the unshifted one.  variant 0: the
+// parameter's generator is inserted in front of its rotation and both shifted
+// values come out of this one run; 1 / 2: the circuit at +shift / -shift.
+struct RunInfo {
+    int32_t param, variant;
+};
+
+// What a sweep workgroup needs for one run, worked out per sample (device side,
+// 8 x 16 bytes): the patched table entries, the measurement mode and where to resume.
+struct RunRec {
+    double m[2];      // new rotation data of the fused 2x2 (table slot ids[0])
+    double fb[2];     // factor for the phase slot ids[1] (in front of the 2x2, or the parameter's own slot)
+    double fa[2];     // factor for the phase slot ids[2] (behind the 2x2)
+    double rho[2];    // pair: ratio of the unit factors left out of the two runs
+    double cs[2];     // pair: cos, sin of half the shift of the rotation angle
+    int32_t ids[4];   // table slots (index into the workgroup's tables, -1: none); ids[3] unused
+    int32_t out[4];   // mode (0: one value, 1: pair), output instance k, resume diagonal stage, resume phase
+    double pad[2];
+};
+
 struct RegHeader {
     int32_t n, T, L, W;          // qubits, thread bits, lane bits, wave bits
     int32_t block;               // threads per workgroup
     int32_t S;                   // states per workgroup (explicit-list kernel)
     int32_t n_uent, n_d1, n_d2;  // per-evaluation table sizes (entries of 16 bytes)
     int32_t n_elems, n_terms, n_ops, n_ddesc, n_xdesc, n_pairs, n_sign, n_params, n_refs, n_phases;
-    int32_t pad2;
+    int32_t n_runs;
     int32_t has_xpose;
     int32_t pad;
     int8_t final_qubit_at_pos[kMaxPos];
     // byte offsets of the arrays inside the device blob
     int64_t off_elems, off_uent, off_d1, off_d2, off_terms, off_ops, off_ddesc, off_xdesc, off_pairs,
-        off_signs, off_params, off_refs, off_phases;
+        off_signs, off_params, off_refs, off_phases, off_runs;
     int64_t total_bytes;
 };
 
@@ -175,6 +195,7 @@ struct RegProgram {
     std::vector<SignTab> signs;
     std::vector<ParamInfo> params;
     std::vector<PatchRef> refs;
+    std::vector<RunInfo> runs;
     std::vector<char> blob;  // header + arrays, as uploaded
     size_t lds_bytes = 0;      // explicit-list kernel (S states per workgroup)
     size_t lds_bytes_psr = 0;  // parameter-shift kernel (one state per workgroup)
