@@ -13,10 +13,9 @@ import sys
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 VARIANTS = [(0, "full kernel"), (1, "no transpositions"), (2, "no register-bit rotations"), (4, "no lane-bit rotations"),
-            (8, "no diagonal stages"), (16, "no measurement"), (32, "no 2x2 recomputation"), (64, "no checkpoint loads"),
-            (128, "no table patching"), (512, "shifts one by one (no pairs)"),
-            (1024, "pair measurement: no state load"), (2048, "pair measurement: no reductions"), (15, "no gates at all"), (127, "gates, measurement, 2x2, loads off"),
-            (255, "... and no patching"), (511, "... and no phase loop")]
+            (8, "no diagonal stages"), (16, "no measurement"), (64, "no checkpoint loads"),
+            (128, "no table patching"), (1024, "pair measurement: no state load"), (15, "no gates at all"), (95, "gates, measurement, loads off"),
+            (223, "... and no patching"), (479, "... and no phase loop")]
 
 if os.environ.get("VQA_SECTION_CHILD"):
     import numpy as np
@@ -44,12 +43,12 @@ if os.environ.get("VQA_SECTION_CHILD"):
         _lib.lib().vqa_debug_stamps(buf, 0)
         v = [float(b) for b in buf]
         runs = B * circ.n_theta * 2  # two sweeps were run
-        names = ["pair: load + products", "pair: sums per thread", "pair: reductions", "pair: finish + store",
-                 "2x2 at theta and variant", "patch + barriers", "(checkpoint load +) phase loop", "measurement (all of it)",
-                 "restore + barrier", "phase: head", "phase: transposition", "phase: register-bit rotations",
+        names = ["per sample: tables + run records", "patch + barriers", "state load + phase loop", "measurement",
+                 "", "", "", "", "", "phase: head", "phase: transposition", "phase: register-bit rotations",
                  "phase: lane-bit rotations", "phase: diagonal stage"]
         for nm, c in zip(names, v):
-            print(f"   {nm:34s} {c / runs:9.0f} cycles per run")
+            if nm:
+                print(f"   {nm:34s} {c / runs:9.0f} cycles per run")
     print(ev0.elapsed_time(ev1))
     sys.exit(0)
 

@@ -391,6 +391,9 @@ __device__ __forceinline__ void apply_ureg(double2 (&amp)[kRegAmps], double u, d
 // FORM: 0 = x <- m0 x +- m1 partner; 1 = x <- x +- m0 partner; 2 = x <- +-m0 x + partner
 template <int LB, int FORM>
 __device__ __forceinline__ void apply_ulane(double2 (&amp)[kRegAmps], double m0, double m1, int lane) {
+    // (the empty volatile statement keeps this two-instruction mask inside the block:
+    // hoisted out of the phase loop it is one more live register per lane bit, and spilled)
+    asm volatile("" : "+v"(lane));
     const unsigned bit = (unsigned)(lane >> LB) & 1u;
     const double ce = flip_if(FORM == 0 ? m1 : m0, bit);
     // the cross-lane moves below read registers that the previous block wrote
@@ -680,14 +683,26 @@ __device__ __forceinline__ void state_sum(double (&v)[NV], const Ctx& cx, double
     }
 }
 
+// Qubit-index bits the thread / each register bit stands for at measurement time
+// (worked out where needed: keeping them across the phase loop costs registers).
+__device__ __forceinline__ void measure_masks(const Prog& pp, int T, int t, unsigned& kt, unsigned (&krb)[kRegBits]) {
+    kt = 0;
+    for (int i = 0; i < T; ++i)
+        if ((t >> i) & 1) kt |= 1u << pp.H->final_qubit_at_pos[kRegBits + i];
+#pragma unroll
+    for (int j = 0; j < kRegBits; ++j) krb[j] = 1u << pp.H->final_qubit_at_pos[j];
+}
+
 // Z-basis observables and the low-bit marginal of the state held in amp, which
 // may carry any common factor: every value is divided by the squared norm.
 // Instance index e, written by the thread with t == 0 (and kept in basev when
 // given).  Returns the squared norm of the state as held.
-__device__ __forceinline__ double measure(const double2 (&amp)[kRegAmps], const RegArgs& a, const Ctx& cx, unsigned kt,
-                                          const unsigned (&krb)[kRegBits], double* red, unsigned& parity, int64_t e,
-                                          bool live, bool valid, double* basev) {
+__device__ __forceinline__ double measure(const double2 (&amp)[kRegAmps], const RegArgs& a, const Prog& pp, const Ctx& cx,
+                                          double* red, unsigned& parity, int64_t e, bool live, bool valid,
+                                          double* basev) {
     const double nanv = __longlong_as_double(0x7ff8000000000000LL);
+    unsigned kt, krb[kRegBits];
+    measure_masks(pp, cx.T, cx.t, kt, krb);
     const int nq = a.obs.n_obs + (a.n_marg_bits > 0 ? (1 << a.n_marg_bits) : 0);
     double pr[kRegAmps];
 #pragma unroll
@@ -753,10 +768,11 @@ __device__ __forceinline__ double measure(const double2 (&amp)[kRegAmps], const 
 // unit factors the engine left out of the two runs and (cos, sin)(kappa/2);
 // e1 = instance index of +kappa (-kappa is e1 + 1).
 __device__ __forceinline__ void measure_pair(double2 (&amp)[kRegAmps], unsigned psi_image, double psi_norm,
-                                             const double2* rec, const double* basev, const RegArgs& a, const Ctx& cx,
-                                             unsigned kt, const unsigned (&krb)[kRegBits], double* red,
-                                             unsigned& parity, int64_t e1, bool valid) {
+                                             const double2* rec, const double* basev, const RegArgs& a, const Prog& pp,
+                                             const Ctx& cx, double* red, unsigned& parity, int64_t e1, bool valid) {
     const double nanv = __longlong_as_double(0x7ff8000000000000LL);
+    unsigned kt, krb[kRegBits];
+    measure_masks(pp, cx.T, cx.t, kt, krb);
     const int nq = a.obs.n_obs + (a.n_marg_bits > 0 ? (1 << a.n_marg_bits) : 0);
     const unsigned toff = cx.tid * (unsigned)sizeof(double2), rstep = cx.nthr * (unsigned)sizeof(double2);
     double pr[kRegAmps];
@@ -839,11 +855,9 @@ __device__ __forceinline__ void measure_pair(double2 (&amp)[kRegAmps], unsigned 
     }
 }
 
-// per-thread constants of a launch: sign masks of every sign table (LDS), and the
-// qubit-index bits the thread / each register bit stands for at measurement time
+// per-thread constants of a launch: sign masks of every sign table (LDS)
 template <int BLOCK>
-__device__ __forceinline__ void thread_constants(const Prog& pp, unsigned short* smask, int T, int t, int tid,
-                                                 unsigned& kt, unsigned (&krb)[kRegBits]) {
+__device__ __forceinline__ void thread_constants(const Prog& pp, unsigned short* smask, int T, int t, int tid) {
     const int n_sign = pp.H->n_sign;
     for (int sg = 0; sg < n_sign; ++sg) {
         const int wi = t >> 5, bi = t & 31;
@@ -863,11 +877,6 @@ __device__ __forceinline__ void thread_constants(const Prog& pp, unsigned short*
         }
         smask[sg * BLOCK + tid] = (unsigned short)m;
     }
-    kt = 0;
-    for (int i = 0; i < T; ++i)
-        if ((t >> i) & 1) kt |= 1u << pp.H->final_qubit_at_pos[kRegBits + i];
-#pragma unroll
-    for (int j = 0; j < kRegBits; ++j) krb[j] = 1u << pp.H->final_qubit_at_pos[j];
 }
 
 // ---- explicit instance list ----------------------------------------------------------
@@ -903,8 +912,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : VQA_WAVES) void k_reg_eva
     cx.flag_mask = -1;
 #endif
 
-    unsigned kt, krb[kRegBits];
-    thread_constants<BLOCK>(pp, smask, T, t, tid, kt, krb);
+    thread_constants<BLOCK>(pp, smask, T, t, tid);
 
     unsigned parity = 0;
     for (int64_t e0 = (int64_t)blockIdx.x * S; e0 < a.E; e0 += (int64_t)gridDim.x * S) {
@@ -925,7 +933,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : VQA_WAVES) void k_reg_eva
         for (int r = 0; r < kRegAmps; ++r) amp[r] = make_double2(0.0, 0.0);
         if (t == 0) amp[0].x = 1.0;
         run_phases<SCALED>(amp, pp, cx, 0, false, false);
-        measure(amp, a, cx, kt, krb, red, parity, e, live, valid, nullptr);
+        measure(amp, a, pp, cx, red, parity, e, live, valid, nullptr);
     }
 }
 
@@ -1006,7 +1014,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : VQA_WAVES) void k_reg_psr
     double2* xbuf = tabs + (size_t)(NU + N1 + N2);
     double* red = (double*)(xbuf + (pp.H->has_xpose ? ((size_t)1 << (n - 1)) : 0));
     double2* pz = (double2*)(red + 64);                   // the current run's record (8 entries)
-    double* basev = (double*)(pz + 16);                   // the unshifted values (80 entries)
+    double2* sav = pz + 8;                                // what the current patch replaced (3 entries, thread 0's)
+    double* basev = (double*)(pz + 16);                   // the unshifted values (79 entries), squared norm of psi
     unsigned short* smask = (unsigned short*)(basev + 80);
 
     Ctx cx;
@@ -1020,8 +1029,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : VQA_WAVES) void k_reg_psr
     cx.flag_mask = ~((a.ablate & 1 ? PH_XPOSE : 0) | (a.ablate & 2 ? PH_UREG0 * 15 : 0) |
                      (a.ablate & 4 ? PH_ULANE0 * 63 : 0) | (a.ablate & 8 ? PH_DIAG : 0));
 #endif
-    unsigned kt, krb[kRegBits];
-    thread_constants<BLOCK>(pp, smask, T, t, tid, kt, krb);
+    thread_constants<BLOCK>(pp, smask, T, t, tid);
 
     // the workgroup's area: ND checkpoints and the unshifted final state, 16 * 2^n bytes each
     cx.image_bytes = 16u << n;
@@ -1060,9 +1068,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : VQA_WAVES) void k_reg_psr
         VQA_STAMP(0)
 
         // run -1 is the unshifted circuit; thread 0 keeps what the current patch replaced
-        double psi_norm = 1.0;
         int old_m = -1, old_b = -1, old_a = -1;
-        double2 sav_m = make_double2(0, 0), sav_b = sav_m, sav_a = sav_m, nx = sav_m;
+        double2 nx = make_double2(0, 0);
         for (int r = -1; r <= NR; ++r) {
             VQA_STAMP0
             __syncthreads();   // the previous run is over (tables free); its successor's record is in pz
@@ -1078,20 +1085,20 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : VQA_WAVES) void k_reg_psr
                 rpc = __builtin_amdgcn_readfirstlane(o.w);
             }
             if (tid == 0 && !VQA_ABL(a, 7)) {
-                if (old_a >= 0) tabs[old_a] = sav_a;
-                if (old_b >= 0) tabs[old_b] = sav_b;
-                if (old_m >= 0) tabs[old_m] = sav_m;
-                if (id_m >= 0) { sav_m = tabs[id_m]; tabs[id_m] = pz[0]; }
+                if (old_a >= 0) tabs[old_a] = sav[2];
+                if (old_b >= 0) tabs[old_b] = sav[1];
+                if (old_m >= 0) tabs[old_m] = sav[0];
+                if (id_m >= 0) { sav[0] = tabs[id_m]; tabs[id_m] = pz[0]; }
                 if (id_b >= 0) {
-                    sav_b = tabs[id_b];
-                    const double2 f = pz[1];
-                    const cplx q = cmul({ sav_b.x, sav_b.y }, { f.x, f.y });
+                    const double2 o = tabs[id_b], f = pz[1];
+                    sav[1] = o;
+                    const cplx q = cmul({ o.x, o.y }, { f.x, f.y });
                     tabs[id_b] = make_double2(q.x, q.y);
                 }
                 if (id_a >= 0) {
-                    sav_a = tabs[id_a];
-                    const double2 f = pz[2];
-                    const cplx q = cmul({ sav_a.x, sav_a.y }, { f.x, f.y });
+                    const double2 o = tabs[id_a], f = pz[2];
+                    sav[2] = o;
+                    const cplx q = cmul({ o.x, o.y }, { f.x, f.y });
                     tabs[id_a] = make_double2(q.x, q.y);
                 }
             }
@@ -1117,12 +1124,12 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : VQA_WAVES) void k_reg_psr
             if (r < 0) store_state(amp, cx.area, (unsigned)ND * cx.image_bytes, BLOCK, tid);
             if (!VQA_ABL(a, 4)) {
                 if (mode == 1) {
-                    measure_pair(amp, (unsigned)ND * cx.image_bytes, psi_norm, pz, basev, a, cx, kt, krb, red, parity,
+                    measure_pair(amp, (unsigned)ND * cx.image_bytes, basev[79], pz, basev, a, pp, cx, red, parity,
                                  j * K + kout, valid);
                 } else {
-                    const double nrm = measure(amp, a, cx, kt, krb, red, parity, j * K + kout, true, valid,
+                    const double nrm = measure(amp, a, pp, cx, red, parity, j * K + kout, true, valid,
                                                r < 0 ? basev : nullptr);
-                    if (r < 0) psi_norm = nrm;
+                    if (r < 0 && tid == 0) basev[79] = nrm;
                 }
             }
             VQA_STAMP(3)
