@@ -187,3 +187,98 @@ def test_large_batch_linearity_property():
     sub = rng.choice(4096, 64, replace=False)
     want, _ = cpu_oracle.eval_batch(c, theta, c.input_angles(x[sub]), obs_list=obs_tuples([z0]))
     assert np.abs(e[sub] - want).max() < TOL
+
+
+def test_headline_sweep_against_explicit_list_and_oracle():
+    """12-qubit depth-10 IBM-HEA (the benchmark circuit): the sweep kernel (checkpoints,
+    pair evaluation) against the explicit-list kernel on every instance of 48 samples,
+    and against the oracle on a subset."""
+    c = create_ibm_HEA_ansatz(12, 10, seed=0)
+    rng = np.random.default_rng(5)
+    theta = rng.uniform(0, 2 * np.pi, c.n_theta)
+    B = 48
+    x = rng.uniform(0, np.pi, (B, 12))
+    d_in = c.upload_inputs(x)
+    z0 = Observable(12); z0.add_operator(1.0, "Z 0")
+    zz = Observable(12); zz.add_operator(0.5, "Z 1 Z 7"); zz.add_operator(-0.25, "")
+    K = 2 * c.n_theta + 1
+    e, m = c.psr_full(theta, d_in, n_sel=B, obs_list=[z0, zz], n_marg_bits=2)
+    e, m = e.cpu().numpy(), m.cpu().numpy()
+    assert np.isfinite(e).all()
+    assert np.abs(m.sum(axis=2) - 1).max() < TOL
+    assert np.abs(e[:, :, 0] - (m[:, :, 0] - m[:, :, 1] + m[:, :, 2] - m[:, :, 3])).max() < TOL
+    si, sp, sv = cpu_oracle.psr_lists(B, c.n_theta)
+    e2, m2 = c.eval_batch(theta, d_in, si, sp, sv, obs_list=[z0, zz], n_marg_bits=2)
+    assert np.abs(e2.cpu().numpy().reshape(B, K, 2) - e).max() < TOL
+    assert np.abs(m2.cpu().numpy().reshape(B, K, 4) - m).max() < TOL
+    pick = rng.choice(B * K, 300, replace=False)
+    want_e, want_m = cpu_oracle.eval_batch(c, theta, c.input_angles(x), si[pick], sp[pick], sv[pick],
+                                           obs_list=obs_tuples([z0, zz]), n_marg_bits=2)
+    assert np.abs(e.reshape(B * K, 2)[pick] - want_e).max() < TOL
+    assert np.abs(m.reshape(B * K, 4)[pick] - want_m).max() < TOL
+
+
+def test_sweep_with_shared_and_scaled_parameters():
+    """Parameters that enter several gates, or with a coefficient: the sweep falls back
+    to explicit shifts or uses the scaled half-angle, and still matches the oracle."""
+    set_engine("reg")
+    c = LearningCircuit(10)
+    for q in range(10):
+        c.add_H_gate(q)
+    p0 = c.add_parametric_RY_gate(0, 0.3)
+    c.add_parametric_RX_gate(1, 0.0, share_with=p0, share_with_coef=-1.5)   # same parameter, other entry
+    for q in range(2, 10):
+        c.add_parametric_RZ_gate(q, 0.1 * q)
+        c.add_parametric_RX_gate(q, 0.2 * q)
+    for q in range(10):
+        c.add_CNOT_gate(q, (q + 1) % 10)
+    for q in range(10):
+        c.add_input_RY_gate(q, lambda x, q=q: x[q % len(x)])
+        c.add_parametric_RY_gate(q, 0.05 * q)
+    for q in range(0, 10, 2):
+        c.add_CZ_gate(q, q + 1)
+    for q in range(10):
+        c.add_parametric_RX_gate(q, 0.3 + 0.01 * q)
+    rng = np.random.default_rng(3)
+    theta = rng.uniform(0, 2 * np.pi, c.n_theta)
+    x = rng.uniform(0, np.pi, (4, 3))
+    ia = c.input_angles(x)
+    obs = random_observables(10, seed=9)
+    si, sp, sv = cpu_oracle.psr_lists(4, c.n_theta)
+    want_e, want_m = cpu_oracle.eval_batch(c, theta, ia, si, sp, sv, obs_list=obs_tuples(obs), n_marg_bits=3)
+    got_e, got_m = c.psr_full(theta, ia, obs_list=obs, n_marg_bits=3)
+    assert np.abs(got_e.reshape(want_e.shape) - want_e).max() < TOL
+    assert np.abs(got_m.reshape(want_m.shape) - want_m).max() < TOL
+
+
+def test_twenty_qubit_streaming_engine():
+    """The 20-qubit configuration's shape on the HBM engine (automatic choice)."""
+    c = create_ibm_HEA_ansatz(20, 1, seed=1)
+    rng = np.random.default_rng(11)
+    theta = rng.uniform(0, 2 * np.pi, c.n_theta)
+    x = rng.uniform(0, np.pi, (2, 20))
+    z0 = Observable(20); z0.add_operator(1.0, "Z 0")
+    zs = Observable(20); zs.add_operator(0.7, "Z 3 Z 19"); zs.add_operator(0.2, "X 5")
+    si = np.array([0, 1, 1], np.int32)
+    sp = np.array([-1, 7, c.n_theta - 1], np.int32)
+    sv = np.array([0.0, 0.5 * np.pi, -0.5 * np.pi])
+    compare(c, theta, x, [z0, zs], 2, si, sp, sv)
+
+
+def test_pauli_sum_ring_hamiltonian():
+    """VQE-shaped case: RY + CZ ring ansatz, transverse-field Ising Pauli sum with X terms."""
+    n = 16
+    c = create_ry_cz_ansatz(n, 6, seed=4)
+    rng = np.random.default_rng(2)
+    theta = rng.uniform(-np.pi, np.pi, c.n_theta)
+    h = Observable(n)
+    for i in range(n):
+        h.add_operator(1.0, f"Z {i} Z {(i + 1) % n}")
+        h.add_operator(1.0, f"X {i}")
+    si, sp, sv = cpu_oracle.psr_lists(1, c.n_theta)
+    keep = rng.choice(len(si), 12, replace=False)
+    keep[0] = 0
+    ia = c.input_angles(np.zeros((1, 1)))
+    want, _ = cpu_oracle.eval_batch(c, theta, ia, si[keep], sp[keep], sv[keep], obs_list=obs_tuples([h]))
+    got, _ = c.eval_batch(theta, ia, si[keep], sp[keep], sv[keep], obs_list=[h])
+    assert np.abs(got - want).max() < 1e-9   # 32 terms of order one: absolute 1e-10 per term

@@ -424,6 +424,7 @@ __device__ __forceinline__ void apply_ulane(double2 (&amp)[kRegAmps], double m0,
 // are then in flight together (with per-amplitude 64-bit vector addresses the
 // register budget makes the compiler reload an address between any two of them).
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 // cache policy of the state-image traffic (aux operand of the buffer builtins).  The
 // non-temporal hint (2) was measured and is slower: the images are re-read many times.
 #ifndef VQA_IMAGE_AUX
@@ -586,20 +587,24 @@ __device__ __forceinline__ void run_phases(double2 (&amp)[kRegAmps], const Prog&
     int first_mask = diag_only_first ? (PH_DIAG | PH_END) : -1;
     VQA_STAMP0
     for (int p = p0;; ++p) {
+        // the whole descriptor in one go (scalar loads issued together, one wait)
+        const VQA_CAS i32x4* dsc = (const VQA_CAS i32x4*)(ph + p);
+        const i32x4 d0 = dsc[0], d1 = dsc[1], d2 = dsc[2], d3 = dsc[3];
+        const int ent[10] = { d0.w, d1.x, d1.y, d1.z, d1.w, d2.x, d2.y, d2.z, d2.w, d3.x };
 #ifdef VQA_PROF
-        const int flags = ph[p].flags & first_mask & cx.flag_mask;
+        const int flags = d0.x & first_mask & cx.flag_mask;
 #else
-        const int flags = ph[p].flags & first_mask;
+        const int flags = d0.x & first_mask;
 #endif
         first_mask = -1;
         if (flags & PH_END) break;
         VQA_STAMP(9)
-        if (flags & PH_XPOSE) do_xpose(amp, pp, cx, ph[p].xdesc);
+        if (flags & PH_XPOSE) do_xpose(amp, pp, cx, d0.y);
         VQA_STAMP(10)
         // rotations: the table entry of the next slot is fetched while the current one runs
-        double2 cs = cx.mat[ph[p].ent[0]], csn;
+        double2 cs = cx.mat[ent[0]], csn;
 #define VQA_REG_SLOT(J)                                           \
-        csn = cx.mat[ph[p].ent[J + 1]];                           \
+        csn = cx.mat[ent[J + 1]];                                 \
         if (flags & (PH_UREG0 << J)) apply_ureg<J>(amp, cs.x, cs.y); \
         cs = csn;
         VQA_REG_SLOT(0) VQA_REG_SLOT(1) VQA_REG_SLOT(2) VQA_REG_SLOT(3)
@@ -608,7 +613,7 @@ __device__ __forceinline__ void run_phases(double2 (&amp)[kRegAmps], const Prog&
         // (with one state per workgroup the two scaled forms are separate optional
         // blocks, not an if / else: each block then updates the amplitudes in place)
 #define VQA_LANE_SLOT(LB)                                                  \
-        csn = cx.mat[ph[p].ent[LB + 5 < 10 ? LB + 5 : 9]];                 \
+        csn = cx.mat[ent[LB + 5 < 10 ? LB + 5 : 9]];                       \
         if constexpr (!SCALED) {                                           \
             if (flags & (PH_ULANE0 << LB)) apply_ulane<LB, 0>(amp, cs.x, cs.y, cx.lane); \
         } else {                                                           \
@@ -622,7 +627,7 @@ __device__ __forceinline__ void run_phases(double2 (&amp)[kRegAmps], const Prog&
 #undef VQA_LANE_SLOT
         VQA_STAMP(12)
         if (flags & PH_DIAG) {
-            const int did = ph[p].ddesc;
+            const int did = d0.z;
             if (ckpt) store_state(amp, cx.area, (unsigned)did * cx.image_bytes, cx.nthr, cx.tid);
             do_diag(amp, pp, cx, did);
         }

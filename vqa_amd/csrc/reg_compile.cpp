@@ -559,6 +559,7 @@ bool reg_compile(int n, int n_theta, const std::vector<vqa_op>& gate_list, RegPr
     H.off_signs = place(P.blob, P.signs);
     H.off_params = place(P.blob, P.params);
     H.off_refs = place(P.blob, P.refs);
+    while (P.blob.size() % 64) P.blob.push_back(0);   // a phase descriptor is one 64-byte scalar load
     H.off_phases = place(P.blob, P.phases);
     H.off_runs = place(P.blob, P.runs);
     while (P.blob.size() % 16) P.blob.push_back(0);
