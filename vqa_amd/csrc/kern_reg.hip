@@ -322,21 +322,29 @@ __device__ __forceinline__ void prep_tables(const RegArgs& a, const Prog& pp, do
 }
 
 // ---- cross-lane partner fetch: value of lane (lane ^ (1 << LB)) -----------------
-template <int LB>
+// On gfx950 a DPP move costs the vector unit as much as an FP64 operation (about four
+// cycles per wave on a SIMD; tools/micro/valu_rates.hip).  The LDS crossbar (ds_swizzle:
+// no memory access, no vector-unit time) can do the same exchange for lane bits 0..4;
+// VQA_SWZ_OF_16 of every 16 amplitudes go that way.  Measured on the 12-qubit sweep:
+// 0 -> 32.0k, 4 -> 31.6k, 8 -> 31.3k, 16 -> 28.0k gradients/s, so the default is 0.
+#ifndef VQA_SWZ_OF_16
+#define VQA_SWZ_OF_16 0
+#endif
+template <int LB, bool SWZ>
 __device__ __forceinline__ int xor_fetch32(int v) {
-    if constexpr (LB == 0) return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);        // quad_perm [1,0,3,2]
+    if constexpr (LB == 5) return __builtin_amdgcn_ds_bpermute(((int)(threadIdx.x & 63) ^ 32) << 2, v);
+    else if constexpr (SWZ || LB == 4) return __builtin_amdgcn_ds_swizzle(v, ((1 << LB) << 10) | 0x1F);   // lane ^ (1 << LB)
+    else if constexpr (LB == 0) return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);        // quad_perm [1,0,3,2]
     else if constexpr (LB == 1) return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
     else if constexpr (LB == 2) {
         int t = __builtin_amdgcn_update_dpp(0, v, 0x104, 0xF, 0x5, false);  // row_shl:4 into banks 0,2
         return __builtin_amdgcn_update_dpp(t, v, 0x114, 0xF, 0xA, false);    // row_shr:4 into banks 1,3
-    } else if constexpr (LB == 3) return __builtin_amdgcn_mov_dpp(v, 0x128, 0xF, 0xF, true);  // row_ror:8
-    else if constexpr (LB == 4) return __builtin_amdgcn_ds_swizzle(v, 0x401F);                 // xor 16 within 32
-    else return __builtin_amdgcn_ds_bpermute(((int)(threadIdx.x & 63) ^ 32) << 2, v);
+    } else return __builtin_amdgcn_mov_dpp(v, 0x128, 0xF, 0xF, true);  // row_ror:8
 }
-template <int LB>
+template <int LB, bool SWZ>
 __device__ __forceinline__ double xor_fetch(double v) {
-    const int lo = xor_fetch32<LB>(__double2loint(v));
-    const int hi = xor_fetch32<LB>(__double2hiint(v));
+    const int lo = xor_fetch32<LB, SWZ>(__double2loint(v));
+    const int hi = xor_fetch32<LB, SWZ>(__double2hiint(v));
     return __hiloint2double(hi, lo);
 }
 
@@ -391,9 +399,6 @@ __device__ __forceinline__ void apply_ureg(double2 (&amp)[kRegAmps], double u, d
 // FORM: 0 = x <- m0 x +- m1 partner; 1 = x <- x +- m0 partner; 2 = x <- +-m0 x + partner
 template <int LB, int FORM>
 __device__ __forceinline__ void apply_ulane(double2 (&amp)[kRegAmps], double m0, double m1, int lane) {
-    // (the empty volatile statement keeps this two-instruction mask inside the block:
-    // hoisted out of the phase loop it is one more live register per lane bit, and spilled)
-    asm volatile("" : "+v"(lane));
     const unsigned bit = (unsigned)(lane >> LB) & 1u;
     const double ce = flip_if(FORM == 0 ? m1 : m0, bit);
     // the cross-lane moves below read registers that the previous block wrote
@@ -401,21 +406,36 @@ __device__ __forceinline__ void apply_ulane(double2 (&amp)[kRegAmps], double m0,
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_nop 1");
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int r = 0; r < kRegAmps; ++r) {
-        const double pr = xor_fetch<LB>(amp[r].x);
-        const double pi = xor_fetch<LB>(amp[r].y);
-        if constexpr (FORM == 0) {
-            lane_upd(amp[r].x, pr, m0, ce);
-            lane_upd(amp[r].y, pi, m0, ce);
-        } else if constexpr (FORM == 1) {
-            lane_upd_a(amp[r].x, pr, ce);
-            lane_upd_a(amp[r].y, pi, ce);
-        } else {
-            lane_upd_b(amp[r].x, pr, ce);
-            lane_upd_b(amp[r].y, pi, ce);
-        }
+#define VQA_LANE_UPD(R, PR, PI)                                \
+    {                                                          \
+        if constexpr (FORM == 0) {                             \
+            lane_upd(amp[R].x, PR, m0, ce);                    \
+            lane_upd(amp[R].y, PI, m0, ce);                    \
+        } else if constexpr (FORM == 1) {                      \
+            lane_upd_a(amp[R].x, PR, ce);                      \
+            lane_upd_a(amp[R].y, PI, ce);                      \
+        } else {                                               \
+            lane_upd_b(amp[R].x, PR, ce);                      \
+            lane_upd_b(amp[R].y, PI, ce);                      \
+        }                                                      \
     }
+    // crossbar fetches first: they travel while the DPP part runs
+    constexpr int NS = (LB < 5) ? VQA_SWZ_OF_16 : 0, ND = kRegAmps - NS;
+    double sr[NS > 0 ? NS : 1], si[NS > 0 ? NS : 1];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        sr[k] = xor_fetch<LB, true>(amp[ND + k].x);
+        si[k] = xor_fetch<LB, true>(amp[ND + k].y);
+    }
+#pragma unroll
+    for (int r = 0; r < ND; ++r) {
+        const double pr = xor_fetch<LB, false>(amp[r].x);
+        const double pi = xor_fetch<LB, false>(amp[r].y);
+        VQA_LANE_UPD(r, pr, pi)
+    }
+#pragma unroll
+    for (int k = 0; k < NS; ++k) VQA_LANE_UPD(ND + k, sr[k], si[k])
+#undef VQA_LANE_UPD
 }
 
 // State images in global memory are [amplitude r][thread] and are moved with buffer
@@ -457,7 +477,17 @@ struct Ctx {
     const double2* ph2;
     char* xbuf;           // LDS transposition buffer
     const unsigned short* smask;  // LDS: [sign table][thread] 16-bit sign masks
-    int T, t, tid, lane, nthr;
+    int T, nthr;
+    int wave, tmask;   // uniform: wave of the workgroup, (1 << T) - 1
+    // Thread ids are worked out where they are needed (two instructions) instead of
+    // being carried through the phase loop in registers.
+    __device__ __forceinline__ int lane() const {
+        int l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        return l;
+    }
+    __device__ __forceinline__ int tid() const { return wave * 64 + lane(); }
+    __device__ __forceinline__ int t() const { return tid() & tmask; }
     int xc_id, xc_wt, xc_rt;      // cached per-thread offsets of one transposition descriptor
     __amdgpu_buffer_rsrc_t area;  // sweep: the workgroup's state images (checkpoints, final state)
     unsigned image_bytes;         // size of one image
@@ -473,8 +503,9 @@ __device__ __forceinline__ void do_xpose(double2 (&amp)[kRegAmps], const Prog& p
     const VQA_CAS XDesc* xd = pp.xdesc + xid;
     if (xid != cx.xc_id) {
         int wt = 0, rt = 0;
+        const int t = cx.t();
         for (int i = 0; i < cx.T; ++i) {
-            const int m = -((cx.t >> i) & 1);
+            const int m = -((t >> i) & 1);
             wt ^= m & xd->wconst[kRegBits + i];
             rt ^= m & xd->rconst[kRegBits + i];
         }
@@ -506,17 +537,18 @@ __device__ __forceinline__ void do_xpose(double2 (&amp)[kRegAmps], const Prog& p
 __device__ __forceinline__ void do_diag(double2 (&amp)[kRegAmps], const Prog& pp, const Ctx& cx, int did) {
     const VQA_CAS DDesc* dd = pp.ddesc + did;
     const double2* p1 = cx.ph1 + dd->ph1_base;
+    const int t = cx.t();
     // thread-only factor
     cplx F = { 1.0, 0.0 };
     for (int i = 0; i < cx.T; ++i) {
         const double2 p = p1[kRegBits + i];
-        F = cmul(F, csel_conj({ p.x, p.y }, (unsigned)(cx.t >> i) & 1u));
+        F = cmul(F, csel_conj({ p.x, p.y }, (unsigned)(t >> i) & 1u));
     }
     const int tt_begin = dd->tt_begin, tt_count = dd->tt_count;
     for (int k = 0; k < tt_count; ++k) {
         const int pa = pp.pairs[tt_begin + k].a, pb = pp.pairs[tt_begin + k].b;
         const double2 z = cx.ph2[pp.pairs[tt_begin + k].ph2];
-        F = cmul(F, csel_conj({ z.x, z.y }, (unsigned)((cx.t >> pa) ^ (cx.t >> pb)) & 1u));
+        F = cmul(F, csel_conj({ z.x, z.y }, (unsigned)((t >> pa) ^ (t >> pb)) & 1u));
     }
     // effective phase of each register bit
     cplx pj[kRegBits];
@@ -529,7 +561,7 @@ __device__ __forceinline__ void do_diag(double2 (&amp)[kRegAmps], const Prog& pp
     for (int k = 0; k < rt_count; ++k) {
         const int pa = pp.pairs[rt_begin + k].a, pb = pp.pairs[rt_begin + k].b;
         const double2 z = cx.ph2[pp.pairs[rt_begin + k].ph2];
-        const cplx ze = csel_conj({ z.x, z.y }, (unsigned)(cx.t >> pb) & 1u);
+        const cplx ze = csel_conj({ z.x, z.y }, (unsigned)(t >> pb) & 1u);
 #pragma unroll
         for (int j = 0; j < kRegBits; ++j)
             if (pa == j) pj[j] = cmul(pj[j], ze);
@@ -550,7 +582,7 @@ __device__ __forceinline__ void do_diag(double2 (&amp)[kRegAmps], const Prog& pp
     // CZ / Z signs: bit r of the thread's mask flips entry r
     const int sign_id = dd->sign_id;
     unsigned sm = 0;
-    if (sign_id >= 0) sm = cx.smask[sign_id * cx.nthr + cx.tid];
+    if (sign_id >= 0) sm = cx.smask[sign_id * cx.nthr + cx.tid()];
 #pragma unroll
     for (int r = 0; r < kRegAmps / 2; ++r) {
         const int flip_lo = (int)((sm << (31 - r)) & 0x80000000u);
@@ -615,12 +647,12 @@ __device__ __forceinline__ void run_phases(double2 (&amp)[kRegAmps], const Prog&
 #define VQA_LANE_SLOT(LB)                                                  \
         csn = cx.mat[ent[LB + 5 < 10 ? LB + 5 : 9]];                       \
         if constexpr (!SCALED) {                                           \
-            if (flags & (PH_ULANE0 << LB)) apply_ulane<LB, 0>(amp, cs.x, cs.y, cx.lane); \
+            if (flags & (PH_ULANE0 << LB)) apply_ulane<LB, 0>(amp, cs.x, cs.y, cx.lane()); \
         } else {                                                           \
             const int form_b = __builtin_amdgcn_readfirstlane(__double2hiint(cs.y)); \
             const int run = flags & (PH_ULANE0 << LB);                     \
-            if (run && form_b == 0) apply_ulane<LB, 1>(amp, cs.x, cs.y, cx.lane); \
-            if (run && form_b != 0) apply_ulane<LB, 2>(amp, cs.x, cs.y, cx.lane); \
+            if (run && form_b == 0) apply_ulane<LB, 1>(amp, cs.x, cs.y, cx.lane()); \
+            if (run && form_b != 0) apply_ulane<LB, 2>(amp, cs.x, cs.y, cx.lane()); \
         }                                                                  \
         cs = csn;
         VQA_LANE_SLOT(0) VQA_LANE_SLOT(1) VQA_LANE_SLOT(2) VQA_LANE_SLOT(3) VQA_LANE_SLOT(4) VQA_LANE_SLOT(5)
@@ -628,7 +660,7 @@ __device__ __forceinline__ void run_phases(double2 (&amp)[kRegAmps], const Prog&
         VQA_STAMP(12)
         if (flags & PH_DIAG) {
             const int did = d0.z;
-            if (ckpt) store_state(amp, cx.area, (unsigned)did * cx.image_bytes, cx.nthr, cx.tid);
+            if (ckpt) store_state(amp, cx.area, (unsigned)did * cx.image_bytes, cx.nthr, cx.tid());
             do_diag(amp, pp, cx, did);
         }
         VQA_STAMP(13)
@@ -672,10 +704,10 @@ __device__ __forceinline__ void state_sum(double (&v)[NV], const Ctx& cx, double
 #pragma unroll
     for (int k = 0; k < NV; ++k) v[k] = wave_sum(v[k]);
     if (cx.T > 6) {
-        const int wave = cx.tid >> 6, nwave = cx.nthr >> 6;
+        const int wave = cx.wave, nwave = cx.nthr >> 6;
         double* buf = red + (parity & 1u) * 32;
         parity ^= 1u;
-        if (cx.lane == 0) {
+        if (cx.lane() == 0) {
 #pragma unroll
             for (int k = 0; k < NV; ++k) buf[k * 8 + wave] = v[k];
         }
@@ -707,7 +739,8 @@ __device__ __forceinline__ double measure(const double2 (&amp)[kRegAmps], const 
                                           double* basev) {
     const double nanv = __longlong_as_double(0x7ff8000000000000LL);
     unsigned kt, krb[kRegBits];
-    measure_masks(pp, cx.T, cx.t, kt, krb);
+    const int t = cx.t();
+    measure_masks(pp, cx.T, t, kt, krb);
     const int nq = a.obs.n_obs + (a.n_marg_bits > 0 ? (1 << a.n_marg_bits) : 0);
     double pr[kRegAmps];
 #pragma unroll
@@ -754,7 +787,7 @@ __device__ __forceinline__ double measure(const double2 (&amp)[kRegAmps], const 
             v[0] = w[0];
         }
         const double val = v[0] * inv_norm;
-        if (cx.t == 0 && live) {
+        if (t == 0 && live) {
             if (q < a.obs.n_obs) a.out_expect[e * a.obs.n_obs + q] = valid ? val : nanv;
             else a.out_marginal[(e << a.n_marg_bits) + (q - a.obs.n_obs)] = valid ? val : nanv;
             if (basev) basev[q] = val;
@@ -777,9 +810,10 @@ __device__ __forceinline__ void measure_pair(double2 (&amp)[kRegAmps], unsigned 
                                              const Ctx& cx, double* red, unsigned& parity, int64_t e1, bool valid) {
     const double nanv = __longlong_as_double(0x7ff8000000000000LL);
     unsigned kt, krb[kRegBits];
-    measure_masks(pp, cx.T, cx.t, kt, krb);
+    const int t = cx.t();
+    measure_masks(pp, cx.T, t, kt, krb);
     const int nq = a.obs.n_obs + (a.n_marg_bits > 0 ? (1 << a.n_marg_bits) : 0);
-    const unsigned toff = cx.tid * (unsigned)sizeof(double2), rstep = cx.nthr * (unsigned)sizeof(double2);
+    const unsigned toff = cx.tid() * (unsigned)sizeof(double2), rstep = cx.nthr * (unsigned)sizeof(double2);
     double pr[kRegAmps];
     // amp <- conj(psi) phi, pr <- |phi|^2; the loads of psi run eight ahead
     u32x4 pv[kRegAmps / 2];
@@ -845,7 +879,7 @@ __device__ __forceinline__ void measure_pair(double2 (&amp)[kRegAmps], unsigned 
             state_sum<3>(w, cx, red, parity);
             v[0] = w[0]; v[1] = w[1]; v[2] = w[2];
         }
-        if (cx.t == 0) {
+        if (t == 0) {
             const bool is_obs = q < a.obs.n_obs;
             const size_t o1 = is_obs ? (size_t)e1 * a.obs.n_obs + q : ((size_t)e1 << a.n_marg_bits) + (q - a.obs.n_obs);
             const size_t step = is_obs ? (size_t)a.obs.n_obs : ((size_t)1 << a.n_marg_bits);
@@ -909,7 +943,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : VQA_WAVES) void k_reg_eva
     cx.ph2 = cx.ph1 + N1;
     cx.xbuf = (char*)xbuf;
     cx.smask = smask;
-    cx.T = T; cx.t = t; cx.tid = tid; cx.lane = tid & 63; cx.nthr = BLOCK;
+    cx.T = T; cx.nthr = BLOCK;
+    cx.wave = __builtin_amdgcn_readfirstlane(tid >> 6); cx.tmask = (1 << T) - 1;
     cx.xc_id = -1; cx.xc_wt = 0; cx.xc_rt = 0;
     cx.area = __builtin_amdgcn_make_buffer_rsrc((void*)nullptr, 0, 0, 0x00020000);
     cx.image_bytes = 0;
@@ -1027,7 +1062,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : VQA_WAVES) void k_reg_psr
     cx.mat = tabs; cx.ph1 = tabs + NU; cx.ph2 = tabs + NU + N1;
     cx.xbuf = (char*)xbuf;
     cx.smask = smask;
-    cx.T = T; cx.t = t; cx.tid = tid; cx.lane = tid & 63; cx.nthr = BLOCK;
+    cx.T = T; cx.nthr = BLOCK;
+    cx.wave = __builtin_amdgcn_readfirstlane(tid >> 6); cx.tmask = (1 << T) - 1;
     cx.xc_id = -1; cx.xc_wt = 0; cx.xc_rt = 0;
 
 #ifdef VQA_PROF
@@ -1112,7 +1148,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : VQA_WAVES) void k_reg_psr
             __syncthreads();
             VQA_STAMP(1)
             // the next run's record travels while this run computes
-            if (r + 1 < NR && cx.lane < 8) nx = recs[(size_t)(r + 1) * 8 + cx.lane];
+            if (r + 1 < NR && (tid & 63) < 8) nx = recs[(size_t)(r + 1) * 8 + (tid & 63)];
 
             double2 amp[kRegAmps];
             int pc0 = 0;
