@@ -763,7 +763,8 @@ __device__ __forceinline__ double measure(const double2 (&amp)[kRegAmps], const 
 #pragma unroll
                     for (int j = 0; j < kRegBits; ++j)
                         if (r & (1 << j)) rp += __popc(krb[j] & z);
-                    part += flip_if(pr[r], rp & 1u);
+                    const double sg = __hiloint2double((int)(0x3FF00000u | ((rp & 1u) << 31)), 0);
+                    part = fma(sg, pr[r], part);
                 }
                 v[0] += a.obs.coef[tm] * part;
             }
@@ -775,7 +776,7 @@ __device__ __forceinline__ double measure(const double2 (&amp)[kRegAmps], const 
 #pragma unroll
                 for (int j = 0; j < kRegBits; ++j)
                     if (r & (1 << j)) k |= krb[j];
-                v[0] += ((k & M1) == m) ? pr[r] : 0.0;
+                v[0] = fma((k & M1) == m ? 1.0 : 0.0, pr[r], v[0]);
             }
         }
         if (q == 0) {
@@ -815,21 +816,24 @@ __device__ __forceinline__ void measure_pair(double2 (&amp)[kRegAmps], unsigned 
     const int nq = a.obs.n_obs + (a.n_marg_bits > 0 ? (1 << a.n_marg_bits) : 0);
     const unsigned toff = cx.tid() * (unsigned)sizeof(double2), rstep = cx.nthr * (unsigned)sizeof(double2);
     double pr[kRegAmps];
-    // amp <- conj(psi) phi, pr <- |phi|^2; the loads of psi run eight ahead
-    u32x4 pv[kRegAmps / 2];
+    // amp <- conj(psi) phi, pr <- |phi|^2; the loads of psi run four ahead.  (The
+    // scheduling fences keep that order: left alone, the compiler issues all sixteen
+    // loads at once and spills the state to make room for them.)
+    u32x4 pv[4];
 #pragma unroll
-    for (int r = 0; r < kRegAmps / 2; ++r)
+    for (int r = 0; r < 4; ++r)
         pv[r] = __builtin_amdgcn_raw_buffer_load_b128(cx.area, toff, psi_image + r * rstep, VQA_IMAGE_AUX);
-#pragma unroll
-    for (int r = 0; r < kRegAmps; ++r) pr[r] = amp[r].x * amp[r].x + amp[r].y * amp[r].y;
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int r = 0; r < kRegAmps; ++r) {
-        const u32x4 cur = pv[r & 7];
-        if (r + 8 < kRegAmps)
-            pv[r & 7] = __builtin_amdgcn_raw_buffer_load_b128(cx.area, toff, psi_image + (r + 8) * rstep, VQA_IMAGE_AUX);
+        const u32x4 cur = pv[r & 3];
         const double2 ps = VQA_ABL(a, 10) ? make_double2(1.0, 0.5) : *(const double2*)&cur;
         const double2 ph = amp[r];
+        pr[r] = ph.x * ph.x + ph.y * ph.y;
         amp[r] = make_double2(ps.x * ph.x + ps.y * ph.y, ps.x * ph.y - ps.y * ph.x);
+        if (r + 4 < kRegAmps)
+            pv[r & 3] = __builtin_amdgcn_raw_buffer_load_b128(cx.area, toff, psi_image + (r + 4) * rstep, VQA_IMAGE_AUX);
+        __builtin_amdgcn_sched_barrier(0);
     }
     double inv_norm = 1.0, inv_cross = 1.0;
     for (int q = 0; q < nq; ++q) {
@@ -849,9 +853,12 @@ __device__ __forceinline__ void measure_pair(double2 (&amp)[kRegAmps], unsigned 
 #pragma unroll
                     for (int j = 0; j < kRegBits; ++j)
                         if (r & (1 << j)) rp += __popc(krb[j] & z);
-                    p0 += flip_if(pr[r], rp & 1u);
-                    p1 += flip_if(amp[r].x, rp & 1u);
-                    p2 += flip_if(amp[r].y, rp & 1u);
+                    // (a +-1 weight in a fused multiply-add: sign-flipped copies of the
+                    // values would all be alive at once and spill)
+                    const double sg = __hiloint2double((int)(0x3FF00000u | ((rp & 1u) << 31)), 0);
+                    p0 = fma(sg, pr[r], p0);
+                    p1 = fma(sg, amp[r].x, p1);
+                    p2 = fma(sg, amp[r].y, p2);
                 }
                 const double cf = a.obs.coef[tm];
                 v[0] += cf * p0; v[1] += cf * p1; v[2] += cf * p2;
@@ -864,10 +871,10 @@ __device__ __forceinline__ void measure_pair(double2 (&amp)[kRegAmps], unsigned 
 #pragma unroll
                 for (int j = 0; j < kRegBits; ++j)
                     if (r & (1 << j)) k |= krb[j];
-                const bool in = (k & M1) == m;
-                v[0] += in ? pr[r] : 0.0;
-                v[1] += in ? amp[r].x : 0.0;
-                v[2] += in ? amp[r].y : 0.0;
+                const double w = (k & M1) == m ? 1.0 : 0.0;
+                v[0] = fma(w, pr[r], v[0]);
+                v[1] = fma(w, amp[r].x, v[1]);
+                v[2] = fma(w, amp[r].y, v[2]);
             }
         }
         if (q == 0) {
