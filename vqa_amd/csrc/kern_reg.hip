@@ -706,7 +706,7 @@ __device__ __forceinline__ void state_sum(double (&v)[NV], const Ctx& cx, double
     if (cx.T > 6) {
         const int wave = cx.wave, nwave = cx.nthr >> 6;
         double* buf = red + (parity & 1u) * 32;
-        parity ^= 1u;
+        parity = __builtin_amdgcn_readfirstlane(parity ^ 1u);   // (uniform: lives in a scalar register)
         if (cx.lane() == 0) {
 #pragma unroll
             for (int k = 0; k < NV; ++k) buf[k * 8 + wave] = v[k];

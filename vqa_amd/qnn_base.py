@@ -247,11 +247,11 @@ class myQNN_base:
                                            obs_list=self._obs_list())
         return _np(e)[:, 0]
 
-    def _psr_all(self, params, idx):
+    def _psr_all(self, params, idx, keep_on_device=False):
         """Exact <Z0> of the 2P+1 parameter-shift instances of each selected training sample: [B, 2P+1]."""
         theta = np.asarray(params[:self.n_c_params], dtype=np.float64)
         e, _ = self.circuit.psr_full(theta, self._handle("train"), sel=np.asarray(idx, np.int32), obs_list=self._obs_list())
-        return _np(e)[:, :, 0]
+        return e[:, :, 0] if keep_on_device else _np(e)[:, :, 0]
 
     # ---- per-sample statistics (myQNNs_base.py:715-738, 799-905) ----------------------
     def _unbiased_powerE_Pauli(self, sample_mean, n_samples, order=4, unbiased=False):
@@ -516,6 +516,11 @@ class myQNN_base:
         """myQNNs_base.py:1346-1395: grad[i] = mean((w E0 - y) w (E+ - E-)), grad[-1] = mean(2(-y E0 + w E0^2_ub))."""
         grad = np.zeros_like(params)
         min_approx, wt_dist, eval_ind, y_eval = self._batch_setup(mini_batch_size, option_min_approx, option_weight)
+        if min_approx == -10:
+            # no random numbers in this mode: the products and means are taken where the
+            # expectation values are (on the GPU with the HIP circuit) and only the
+            # gradient and the unshifted values come back
+            return self._exact_grad(params, eval_ind, y_eval)
         E = self._psr_all(params, eval_ind)
         n_shots_data_list = np.floor(n_shots_list[-1] * wt_dist).astype(int)
         w = params[-1]
@@ -530,6 +535,32 @@ class myQNN_base:
             EXm = self._estimate(E[:, 2 + 2 * i], n_shots_data_list, min_approx, order=2, unbiased=True)
             grad[i] = np.mean((w * EX0_list - y_eval) * w * (EXp[0] - EXm[0]))
         return grad
+
+    def _exact_grad(self, params, eval_ind, y_eval):
+        """MSE_grad_eval in exact mode (min_approx_shots = -10; myQNNs_base.py:874-882 makes every
+        estimate the exact value), with the same counters."""
+        from .distributed import mse_gradient_sums
+
+        E = self._psr_all(params, eval_ind, keep_on_device=True)
+        B, K = int(E.shape[0]), int(E.shape[1])
+        w = float(params[-1])
+        if hasattr(E, "detach"):
+            import torch
+
+            y = torch.from_numpy(np.ascontiguousarray(y_eval, dtype=np.float64)).to(E.device)
+            sums = mse_gradient_sums(E, y, w)
+            grad = (sums / B).cpu().numpy()
+            e0 = E[:, 0].cpu().numpy()
+        else:
+            grad = mse_gradient_sums(E, np.asarray(y_eval, dtype=float), w) / B
+            e0 = E[:, 0]
+        self.circuit_counter[0] += B * K
+        self.call_counter[0] += B * K
+        self.cache_train_pred = w * e0
+        self.cache_y_train_eval = y_eval
+        out = np.zeros_like(params)
+        out[:] = grad
+        return out
 
     def MSE_loss_eval(self, params, n_shots, mini_batch_size=None, option_min_approx=None, option_weight=None):
         """myQNNs_base.py:1397-1419."""
