@@ -223,16 +223,23 @@ def measured_peaks(device):
     return out
 
 
-def hbm_traffic_per_launch(evals):
-    """HBM bytes per launch of the sweep kernel from the committed rocprofv3 PMC pass
-    of this same command (profiles/hbm_traffic.json: bytes per circuit evaluation,
-    corrected as the micro-architecture guide prescribes); None when absent."""
+def profiled(key):
+    """A per-evaluation figure of the sweep kernel from the committed rocprofv3 PMC passes
+    of this same command (profiles/hbm_traffic.json, written by tools/hbm_traffic.py);
+    None when absent."""
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f)["hbm_bytes_per_eval"] * evals
+            return float(json.load(f)[key])
     except (OSError, KeyError, ValueError):
         return None
+
+
+def hbm_traffic_per_launch(evals):
+    """HBM bytes per launch (PMC FETCH_SIZE / WRITE_SIZE, corrected as the micro-architecture
+    guide prescribes)."""
+    per_eval = profiled("hbm_bytes_per_eval")
+    return None if per_eval is None else per_eval * evals
 
 
 def roofline(bytes_alg, flops_alg, evals, kern_ms, measured):
@@ -257,6 +264,12 @@ def roofline(bytes_alg, flops_alg, evals, kern_ms, measured):
         "lds": {"achieved": gbs, "peak": LDS_PEAK_GBS, "unit": "GB/s", "frac": gbs / LDS_PEAK_GBS},
         "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS},
     }
+    ex = profiled("fp64_flops_per_eval")
+    if ex is not None:
+        # what the kernel executes (PMC instruction counts of the profiled run) at the rate measured now
+        r["executed"] = {"achieved": ex * per_s / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ex * per_s / 1e12 / FP64_PEAK_TFLOPS, "fp64_flops_per_eval": ex,
+                         "fp64_issue_frac": profiled("fp64_wave_instr_per_eval") * per_s * 4.0 / (1024 * 2.4e9)}
     if measured:
         r["measured_peaks"] = measured
         if "fp64_fma_tflops" in measured:

@@ -175,6 +175,12 @@ int vqa_eval_batch_dev(vqa_circuit* c, int device, void* stream,
  * oracles: base evaluation + for each parameter the +/- pi/2 pair over the
  * mini-batch (vqa/QNN/myQNNs_base.py:1370-1394, 1469-1530;
  * vqa/QNN/myQNNs_classifier.py:1116-1156).
+ *
+ * Sweeps (and every call served by the streaming engine, n >= 14) use a
+ * workspace the library keeps per device and grows on demand: calls that
+ * overlap in time on ONE device, from different threads or streams, race on
+ * it.  Order them on one stream or synchronise between them; different
+ * devices are independent.
  */
 int vqa_psr_full(vqa_circuit* c, int device,
                  const double* theta, const double* input_angles, int B,

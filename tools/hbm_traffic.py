@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/hbm_traffic.json from the FETCH_SIZE / WRITE_SIZE passes of tools/prof.sh.
+"""profiles/hbm_traffic.json from the FETCH_SIZE / WRITE_SIZE / FP64 instruction passes of tools/prof.sh.
 
 usage: tools/hbm_traffic.py gpurun_out/prof_<tag> <launches> <evals per launch> <kernel substring>
 
@@ -21,12 +21,16 @@ def total(name):
     return s
 
 
+fma, mul, add = (total("SQ_INSTS_VALU_%s_F64" % k) / launches for k in ("FMA", "MUL", "ADD"))
 fetch = 2.0 * 1024.0 * total("FETCH_SIZE") / launches
 write = 1024.0 * total("WRITE_SIZE") / launches
 out = {
     "kernel": kern, "launches_profiled": launches, "evals_per_launch": evals,
     "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
     "hbm_bytes_per_launch": fetch + write, "hbm_bytes_per_eval": (fetch + write) / evals,
+    # executed FP64 work of the kernel (wave64 instructions; an FMA is two flops per lane)
+    "fp64_wave_instr_per_eval": (fma + mul + add) / evals,
+    "fp64_flops_per_eval": 64.0 * (2.0 * fma + mul + add) / evals,
     "corrections": "FETCH_SIZE x2 (gfx950 wide loads), both counters KiB -> bytes",
     "source": os.path.basename(os.path.normpath(d)),
 }
