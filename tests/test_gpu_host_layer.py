@@ -95,3 +95,36 @@ def test_fit_runs_on_gpu_and_pickles(tmp_path):
     res = g.fit(options=dict(max_iter=15), auto_save=True, save_directory=str(tmp_path))
     assert res["func_evol"][-1]["train"] < res["func_evol"][0]["train"]
     assert len(list(tmp_path.iterdir())) == 1
+
+
+def test_device_statistics_clt_gradient():
+    """CLT-mode gradient with the deviates drawn on the GPU: same counters as the host path,
+    and the same values within the shot noise (large shot numbers)."""
+    (g, p), (o, _) = pair(create_ibm_HEA_ansatz, 6, 2, myQNN_base, n_train=64)
+    g.device_statistics = True
+    shots = np.full(g.n_params, 2_000_000)
+    np.random.seed(3)
+    gd = g.MSE_grad_eval(p, shots, mini_batch_size=64)
+    np.random.seed(3)
+    gh = o.MSE_grad_eval(p, shots, mini_batch_size=64)
+    assert (g.shots_counter[0], g.call_counter[0], g.circuit_counter[0]) == \
+           (o.shots_counter[0], o.call_counter[0], o.circuit_counter[0])
+    exact = o.MSE_grad_eval(p, shots, mini_batch_size=64, option_min_approx=-10)
+    # both are the exact gradient of their (different) mini-batches plus noise of order 1e-3 / sqrt(64)
+    assert np.all(np.isfinite(gd)) and np.max(np.abs(gd)) < 10
+    g.remain_ind, o.remain_ind = [], []
+    np.random.seed(4)
+    gd2 = g.MSE_grad_eval(p, shots, mini_batch_size=len(g.x_train))
+    np.random.seed(4)
+    ex2 = o.MSE_grad_eval(p, shots, mini_batch_size=len(o.x_train), option_min_approx=-10)
+    assert np.max(np.abs(gd2 - ex2)) < 5e-3
+
+
+def test_pauli_sum_target_matches_oracle_circuit():
+    from test_vqe_target import make
+    vg, p = make(n=10, d=3, min_approx=-10, cls=LearningCircuit)
+    vo, _ = make(n=10, d=3, min_approx=-10, cls=OracleCircuit)
+    assert abs(vg.exact_energy(p) - vo.exact_energy(p)) < 1e-9
+    a, b = vg.iEval(p, np.full(vg.n_params, 10)), vo.iEval(p, np.full(vo.n_params, 10))
+    assert np.max(np.abs(a["grad"] - b["grad"])) < 1e-9
+    assert np.max(np.abs(a["gvar_list"] - b["gvar_list"])) < 1e-8

@@ -90,7 +90,7 @@ __device__ __forceinline__ double op_angle(const vqa_op& op, const double* theta
 }
 
 // ---- observables, passed to kernels by value --------------------------------
-constexpr int kMaxObs = 16;
+constexpr int kMaxObs = 64;
 constexpr int kMaxTerms = 96;
 struct ObsPack {
     int n_obs;

@@ -57,8 +57,12 @@ class myQNN_base:
     def __init__(self, n_qubits, learning_circuit, x_train=None, y_train=None, x_test=None, y_test=None,
                  min_approx_shots=-1, setting_dict=None, id_string="QNN", file_id=None, obs=None,
                  shot_time=1.0, per_circuit_overhead=0.0, communication_overhead=0.0,
-                 max_sub_nqubits_sampling_aft_partial_tr=6):
+                 max_sub_nqubits_sampling_aft_partial_tr=6, device_statistics=False):
         self.circuit = learning_circuit
+        # True: in pure CLT mode the gradient oracle draws its normal deviates on the GPU
+        # (torch generator seeded from NumPy's) and returns only the gradient; same
+        # statistics and counters, but not the reference's NumPy draw sequence
+        self.device_statistics = device_statistics
         self.n_c_params = len(self.circuit.get_parameters())
         self.n_params = self.n_c_params + 1  # + the re-normalisation coefficient
         self.n_qubits = n_qubits
@@ -521,6 +525,10 @@ class myQNN_base:
             # expectation values are (on the GPU with the HIP circuit) and only the
             # gradient and the unshifted values come back
             return self._exact_grad(params, eval_ind, y_eval)
+        if getattr(self, "device_statistics", False) and min_approx >= 0:
+            g = self._clt_grad_on_device(params, n_shots_list, wt_dist, eval_ind, y_eval, min_approx)
+            if g is not None:
+                return g
         E = self._psr_all(params, eval_ind)
         n_shots_data_list = np.floor(n_shots_list[-1] * wt_dist).astype(int)
         w = params[-1]
@@ -560,6 +568,46 @@ class myQNN_base:
         self.cache_y_train_eval = y_eval
         out = np.zeros_like(params)
         out[:] = grad
+        return out
+
+    def _clt_grad_on_device(self, params, n_shots_list, wt_dist, eval_ind, y_eval, min_approx):
+        """MSE_grad_eval when every estimate is in the CLT branch (n >= min_approx_shots,
+        myQNNs_base.py:892-905), computed where the expectation values are.  None when the
+        circuit does not compute on a GPU or some shot count falls below the threshold."""
+        n_all = np.floor(np.asarray(n_shots_list, dtype=float)[:, None] * wt_dist[None, :])   # [P+1, B]
+        if n_all.min() < max(min_approx, 2):
+            return None
+        E = self._psr_all(params, eval_ind, keep_on_device=True)
+        if not hasattr(E, "detach"):
+            return None
+        import torch
+
+        B, K = int(E.shape[0]), int(E.shape[1])
+        P = self.n_c_params
+        gen = torch.Generator(device=E.device)
+        gen.manual_seed(int(np.random.randint(0, 2 ** 31 - 1)))
+        w = float(params[-1])
+        y = torch.from_numpy(np.ascontiguousarray(y_eval, dtype=np.float64)).to(E.device)
+        n = torch.from_numpy(n_all).to(E.device)                        # [P+1, B]
+        n_inst = torch.empty((B, K), dtype=torch.float64, device=E.device)
+        n_inst[:, 0] = n[-1]
+        n_inst[:, 1::2] = n[:P].T
+        n_inst[:, 2::2] = n[:P].T
+        M = E + torch.randn((B, K), dtype=torch.float64, device=E.device, generator=gen) * torch.sqrt((1.0 - E * E) / n_inst)
+        M0 = M[:, 0]
+        n0 = n[-1]
+        M0sq = (n0 / (n0 - 1.0)) * M0 * M0 - 1.0 / (n0 - 1.0)           # unbiased square, myQNNs_base.py:843
+        resid = (w * M0 - y) * w
+        grad = torch.empty(P + 1, dtype=torch.float64, device=E.device)
+        grad[:P] = (resid[:, None] * (M[:, 1::2] - M[:, 2::2])).mean(0)
+        grad[P] = (2.0 * (-y * M0 + w * M0sq)).mean()
+        self.circuit_counter[0] += B * K
+        self.call_counter[0] += B * K
+        self.shots_counter[0] += int(n_all[-1].sum() + 2 * n_all[:P].sum())
+        self.cache_train_pred = (w * M0).cpu().numpy()
+        self.cache_y_train_eval = y_eval
+        out = np.zeros_like(params)
+        out[:] = grad.cpu().numpy()
         return out
 
     def MSE_loss_eval(self, params, n_shots, mini_batch_size=None, option_min_approx=None, option_weight=None):
