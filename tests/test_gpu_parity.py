@@ -12,7 +12,7 @@ from helpers import TOL, obs_tuples, random_circuit, random_observables
 
 pytestmark = pytest.mark.gpu
 
-ENGINES = {"lds": 1, "reg": 2, "hbm": 3}
+ENGINES = {"lds": 1, "reg": 2, "hbm": 3, "pergate": 4}
 
 
 @pytest.fixture(autouse=True)
@@ -81,7 +81,7 @@ def test_random_circuits_all_gate_kinds(engine, n):
 @pytest.mark.parametrize("engine,n,d", [("reg", 4, 2), ("reg", 6, 5), ("reg", 9, 2), ("reg", 11, 2), ("reg", 12, 2),
                                         ("reg", 12, 10), ("reg", 13, 1),
                                         ("lds", 4, 2), ("lds", 6, 5), ("lds", 12, 2), ("lds", 13, 1),
-                                        ("hbm", 6, 2), ("hbm", 14, 1), ("hbm", 16, 1)])
+                                        ("hbm", 6, 2), ("hbm", 14, 1), ("hbm", 16, 1), ("hbm", 17, 2), ("pergate", 14, 1)])
 def test_ibm_hea_full_parameter_shift(engine, n, d):
     set_engine(engine)
     c = create_ibm_HEA_ansatz(n, d, seed=0)
@@ -282,3 +282,23 @@ def test_pauli_sum_ring_hamiltonian():
     want, _ = cpu_oracle.eval_batch(c, theta, ia, si[keep], sp[keep], sv[keep], obs_list=obs_tuples([h]))
     got, _ = c.eval_batch(theta, ia, si[keep], sp[keep], sv[keep], obs_list=[h])
     assert np.abs(got - want).max() < 1e-9   # 32 terms of order one: absolute 1e-10 per term
+
+
+def test_tiled_passes_against_gate_sweeps_22_qubits():
+    """Beyond what the oracle finishes quickly: the tiled passes of the HBM engine against its
+    one-sweep-per-gate form (independent kernels) on a 22-qubit circuit with all gate kinds."""
+    res = []
+    for engine in ("hbm", "pergate"):
+        set_engine(engine)
+        c = random_circuit(LearningCircuit, 22, 120, seed=77)
+        rng = np.random.default_rng(8)
+        theta = rng.uniform(-3, 3, c.n_theta)
+        x = rng.uniform(-1, 1, (2, 3))
+        obs = random_observables(22, seed=5, xy=True)
+        sp = np.array([-1, 2, 4], np.int32)
+        e, m = c.eval_batch(theta, c.input_angles(x), np.array([0, 1, 1], np.int32), sp,
+                            np.array([0.0, 0.5 * np.pi, -0.5 * np.pi]), obs_list=obs, n_marg_bits=3)
+        res.append((e, m))
+    assert np.abs(res[0][0] - res[1][0]).max() < TOL
+    assert np.abs(res[0][1] - res[1][1]).max() < TOL
+    assert np.abs(res[0][1].sum(axis=1) - 1).max() < TOL

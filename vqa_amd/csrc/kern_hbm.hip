@@ -1,11 +1,18 @@
 // Engine 3: HBM-streaming statevector kernels (any n; used for n >= 14).
 //
 // States live in a library-owned HBM workspace, C instances at a time
-// (C * 2^n * 16 bytes).  Every gate of the submitted list is one coalesced
-// sweep over the chunk: dense 1-qubit gates as amplitude-pair sweeps, RZ / CZ /
-// Z as in-place phase or sign sweeps, CNOT as a conditional pair swap.  The
-// observables are reduced in two deterministic stages (per-block partials,
-// then one finishing block per instance).
+// (C * 2^n * 16 bytes).  For n >= 13 the gate list is cut into PASSES: a pass
+// names 12 "tile" qubits (the four lowest plus eight others); a workgroup
+// gathers the 4096 amplitudes that differ only in those bits into LDS, applies
+// every gate of the pass there (gates on the tile qubits; diagonal gates and
+// controls may also sit on the other, "outer" qubits, whose bits are fixed
+// for the workgroup) and writes the tile back: one read and one write of the
+// state per pass instead of per gate (an IBM-HEA layer on 20 qubits is one
+// pass instead of 80 gate sweeps).  Below 13 qubits, or with engine 4, every
+// gate is one coalesced sweep over the chunk: dense 1-qubit gates as
+// amplitude-pair sweeps, RZ / CZ / Z as in-place phase or sign sweeps, CNOT as
+// a conditional pair swap.  The observables are reduced in two deterministic
+// stages (per-block partials, then one finishing block per instance).
 //
 // Replaces, per instance, LearningCircuit.run(x) + Observable expectation
 // (vqa/QNN/myQNNs_base.py:692-704, 907-914) for registers that do not fit a
@@ -120,6 +127,276 @@ __global__ __launch_bounds__(kT) void k_diag(double2* st, int n, int C, int kind
     }
 }
 
+
+// ---- tiled passes -----------------------------------------------------------------
+constexpr int kTileBits = 12;                 // qubits of a tile
+constexpr int kTileAmps = 1 << kTileBits;
+constexpr int kGateBatch = 256;               // gates of a pass staged in LDS (passes are cut to fit)
+constexpr int kTileLow = 4;                   // the lowest qubits belong to every tile (256-byte runs in HBM)
+
+// one gate of a pass: positions < 32 are tile positions, 32 + q is outer qubit q, -1 unused
+struct TileGate {
+    int32_t kind, p0, p1, g;                  // g = index into the angle table
+};
+// Gates of a pass are grouped into segments, each one sweep over the tile in LDS:
+// the 1-qubit gates that follow each other on one tile qubit (one fused 2x2), a run of
+// diagonal gates on any qubits (one phase per amplitude), or a single CNOT.
+enum { SEG_1Q = 0, SEG_DIAG = 1, SEG_CNOT = 2 };
+struct TileSeg {
+    int32_t type, pos, begin, count;          // gates [begin, begin + count) of the pass
+};
+struct TilePassArgs {
+    int n, C, n_ops;
+    int tq[kTileBits];                        // tile position -> qubit (ascending)
+    int oq[32];                               // outer bit number -> qubit (ascending)
+    int n_outer;
+    const TileGate* gates;
+    int n_gates;
+    const TileSeg* segs;
+    int n_segs;
+    const double2* tab;
+};
+
+struct c2 {
+    double x, y;
+};
+__device__ __forceinline__ c2 cm(c2 a, c2 b) { return { a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x }; }
+__device__ __forceinline__ c2 ca(c2 a, c2 b) { return { a.x + b.x, a.y + b.y }; }
+
+__device__ __forceinline__ bool gate_bit(int p, int64_t base, int i) {
+    return p >= 32 ? ((base >> (p - 32)) & 1) != 0 : ((i >> p) & 1) != 0;
+}
+
+__global__ __launch_bounds__(kT) void k_tile_pass(double2* st, TilePassArgs a) {
+    extern __shared__ double2 tile[];
+    __shared__ TileGate sg[kGateBatch];
+    __shared__ double2 scs[kGateBatch];
+    __shared__ TileSeg ssg[kGateBatch];
+    __shared__ double2 dtab[128];
+    const int tid = threadIdx.x;
+    const int64_t w = blockIdx.x;             // tile number: the value of the outer bits
+    const int ci = blockIdx.y;
+    int64_t base = 0;
+    for (int j = 0; j < a.n_outer; ++j) base |= ((w >> j) & 1) << a.oq[j];
+    double2* s = st + ((int64_t)ci << a.n);
+    // the gates of the pass and their angles (fetching them one by one from global memory
+    // would put two dependent loads in front of every sweep)
+    for (int k = tid; k < a.n_gates; k += kT) {
+        const TileGate t = a.gates[k];
+        sg[k] = t;
+        scs[k] = a.tab[(int64_t)ci * a.n_ops + t.g];
+    }
+    for (int k = tid; k < a.n_segs; k += kT) ssg[k] = a.segs[k];
+    // gather: local index l (12 bits) -> global index; the low four bits are contiguous
+    for (int k = 0; k < kTileAmps / kT; ++k) {
+        const int l = k * kT + tid;
+        int64_t gidx = base | (l & ((1 << kTileLow) - 1));
+        for (int j = kTileLow; j < kTileBits; ++j) gidx |= (int64_t)((l >> j) & 1) << a.tq[j];
+        tile[l] = s[gidx];
+    }
+    for (int si = 0; si < a.n_segs; ++si) {
+        __syncthreads();
+        const TileSeg sgm = ssg[si];
+        if (sgm.type == SEG_DIAG) {
+            // The phase of amplitude i factors into a part from its low six tile bits (and the
+            // outer bits, fixed here), a part from its high six, and the signs of the CZs that
+            // join the two halves (sgm.pos of them, first in the run).  The two 64-entry tables
+            // are built by 128 threads, then every amplitude takes one complex product.
+            if (tid < 128) {
+                const int half = tid >> 6, i = half ? (tid & 63) << 6 : (tid & 63);
+                c2 ph = { 1.0, 0.0 };
+                bool neg = false;
+                for (int g = sgm.begin + sgm.pos; g < sgm.begin + sgm.count; ++g) {
+                    const TileGate tg = sg[g];
+                    const bool hi = (tg.p0 < 32 && tg.p0 >= 6) || (tg.p1 >= 6 && tg.p1 < 32);
+                    if ((int)hi != half) continue;
+                    if (tg.kind == VQA_GATE_RZ) {
+                        const double2 cs = scs[g];
+                        ph = cm(ph, { cs.x, gate_bit(tg.p0, base, i) ? -cs.y : cs.y });
+                    } else {
+                        bool f = gate_bit(tg.p0, base, i);
+                        if (tg.kind == VQA_GATE_CZ) f = f && gate_bit(tg.p1, base, i);
+                        neg ^= f;
+                    }
+                }
+                if (neg) ph = { -ph.x, -ph.y };
+                dtab[tid] = make_double2(ph.x, ph.y);
+            }
+            __syncthreads();
+            for (int k = 0; k < kTileAmps / kT; ++k) {
+                const int i = k * kT + tid;
+                const double2 lo = dtab[i & 63], hi = dtab[64 + (i >> 6)];
+                c2 ph = cm({ lo.x, lo.y }, { hi.x, hi.y });
+                bool neg = false;
+                for (int g = sgm.begin; g < sgm.begin + sgm.pos; ++g) neg ^= ((i >> sg[g].p0) & (i >> sg[g].p1) & 1) != 0;
+                if (neg) ph = { -ph.x, -ph.y };
+                const double2 v = tile[i];
+                const c2 r = cm({ v.x, v.y }, ph);
+                tile[i] = make_double2(r.x, r.y);
+            }
+        } else if (sgm.type == SEG_1Q) {
+            // product of the group's 2x2s (every thread works it out: a handful of operations)
+            c2 m00 = { 1, 0 }, m01 = { 0, 0 }, m10 = { 0, 0 }, m11 = { 1, 0 };
+            for (int g = sgm.begin; g < sgm.begin + sgm.count; ++g) {
+                const int kind = sg[g].kind;
+                const double c = scs[g].x, sn = scs[g].y;
+                const double r2 = 0.70710678118654752440;
+                c2 g00, g01, g10, g11;
+                switch (kind) {
+                case VQA_GATE_H: g00 = { r2, 0 }; g01 = { r2, 0 }; g10 = { r2, 0 }; g11 = { -r2, 0 }; break;
+                case VQA_GATE_X: g00 = { 0, 0 }; g01 = { 1, 0 }; g10 = { 1, 0 }; g11 = { 0, 0 }; break;
+                case VQA_GATE_Y: g00 = { 0, 0 }; g01 = { 0, -1 }; g10 = { 0, 1 }; g11 = { 0, 0 }; break;
+                case VQA_GATE_Z: g00 = { 1, 0 }; g01 = { 0, 0 }; g10 = { 0, 0 }; g11 = { -1, 0 }; break;
+                case VQA_GATE_RX: g00 = { c, 0 }; g01 = { 0, sn }; g10 = { 0, sn }; g11 = { c, 0 }; break;
+                case VQA_GATE_RY: g00 = { c, 0 }; g01 = { sn, 0 }; g10 = { -sn, 0 }; g11 = { c, 0 }; break;
+                default: /* RZ */ g00 = { c, sn }; g01 = { 0, 0 }; g10 = { 0, 0 }; g11 = { c, -sn }; break;
+                }
+                const c2 n00 = ca(cm(g00, m00), cm(g01, m10)), n01 = ca(cm(g00, m01), cm(g01, m11));
+                const c2 n10 = ca(cm(g10, m00), cm(g11, m10)), n11 = ca(cm(g10, m01), cm(g11, m11));
+                m00 = n00; m01 = n01; m10 = n10; m11 = n11;
+            }
+            const int p = sgm.pos, bit = 1 << p;
+            for (int k = 0; k < kTileAmps / 2 / kT; ++k) {
+                const int pi = k * kT + tid;
+                const int i0 = ((pi >> p) << (p + 1)) | (pi & (bit - 1));
+                const double2 v0 = tile[i0], v1 = tile[i0 | bit];
+                const c2 a0 = { v0.x, v0.y }, a1 = { v1.x, v1.y };
+                const c2 r0 = ca(cm(m00, a0), cm(m01, a1)), r1 = ca(cm(m10, a0), cm(m11, a1));
+                tile[i0] = make_double2(r0.x, r0.y);
+                tile[i0 | bit] = make_double2(r1.x, r1.y);
+            }
+        } else {
+            const TileGate tg = sg[sgm.begin];
+            const int p = tg.p0, bit = 1 << p;
+            for (int k = 0; k < kTileAmps / 2 / kT; ++k) {
+                const int pi = k * kT + tid;
+                const int i0 = ((pi >> p) << (p + 1)) | (pi & (bit - 1));
+                if (gate_bit(tg.p1, base, i0)) {
+                    const double2 v0 = tile[i0], v1 = tile[i0 | bit];
+                    tile[i0] = v1;
+                    tile[i0 | bit] = v0;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int k = 0; k < kTileAmps / kT; ++k) {
+        const int l = k * kT + tid;
+        int64_t gidx = base | (l & ((1 << kTileLow) - 1));
+        for (int j = kTileLow; j < kTileBits; ++j) gidx |= (int64_t)((l >> j) & 1) << a.tq[j];
+        s[gidx] = tile[l];
+    }
+}
+
+// Cuts the gate list into passes.  A gate can run in a pass when its target (for
+// the non-diagonal kinds) is a tile qubit and none of its qubits is held back by
+// an earlier gate that could not run; gates that share no qubit commute, so
+// later gates on other qubits may run ahead of a held-back one.  Inside a pass
+// the gates are grouped into segments with the same argument: a gate joins the
+// last segment that touches its qubits when that is a group it fits into (the
+// 1-qubit group of its own qubit, or, for a diagonal gate, any diagonal run at or
+// behind that point), else it opens a new one.
+struct TilePlan {
+    struct Pass {
+        int tq[kTileBits];
+        std::vector<TileGate> gates;   // in segment order
+        std::vector<TileSeg> segs;
+    };
+    std::vector<Pass> passes;
+    std::vector<TileGate> all_gates;   // images copied to the device: the passes' gates and segments in order
+    std::vector<TileSeg> all_segs;
+};
+
+static void group_segments(TilePlan::Pass& pass, const std::vector<TileGate>& in_order) {
+    struct Seg { int type, pos; std::vector<TileGate> g; };
+    std::vector<Seg> segs;
+    std::map<int, int> last;   // position (tile or 32 + outer qubit) -> last segment touching it
+    auto last_of = [&](int p) { auto it = last.find(p); return it == last.end() ? -1 : it->second; };
+    int last_diag = -1;
+    for (const TileGate& tg : in_order) {
+        const bool diag = tg.kind == VQA_GATE_RZ || tg.kind == VQA_GATE_Z || tg.kind == VQA_GATE_CZ;
+        const int dep = std::max(last_of(tg.p0), tg.p1 >= 0 ? last_of(tg.p1) : -1);
+        int at = -1;
+        if (tg.kind != VQA_GATE_CNOT && tg.kind != VQA_GATE_CZ && tg.p0 < 32 && dep >= 0 && dep == last_of(tg.p0) &&
+            segs[dep].type == SEG_1Q && segs[dep].pos == tg.p0) {
+            at = dep;                                             // the 2x2 group of this qubit
+        } else if (diag && last_diag >= dep && last_diag >= 0) {
+            at = last_diag;                                       // a diagonal run not in front of its dependencies
+        } else {
+            Seg sg;
+            sg.type = tg.kind == VQA_GATE_CNOT ? SEG_CNOT : diag ? SEG_DIAG : SEG_1Q;
+            sg.pos = tg.p0;
+            segs.push_back(sg);
+            at = (int)segs.size() - 1;
+            if (diag) last_diag = at;
+        }
+        segs[at].g.push_back(tg);
+        last[tg.p0] = std::max(last_of(tg.p0), at);
+        if (tg.p1 >= 0) last[tg.p1] = std::max(last_of(tg.p1), at);
+    }
+    for (Seg& sg : segs) {
+        int pos = sg.pos;
+        if (sg.type == SEG_DIAG) {
+            // CZs between the low six and the high six tile bits go first; pos = how many
+            auto cross = [](const TileGate& t) {
+                return t.kind == VQA_GATE_CZ && t.p0 < 32 && t.p1 < 32 && (t.p0 < 6) != (t.p1 < 6);
+            };
+            std::stable_partition(sg.g.begin(), sg.g.end(), cross);
+            pos = (int)std::count_if(sg.g.begin(), sg.g.end(), cross);
+        }
+        pass.segs.push_back(TileSeg{ sg.type, pos, (int)pass.gates.size(), (int)sg.g.size() });
+        pass.gates.insert(pass.gates.end(), sg.g.begin(), sg.g.end());
+    }
+}
+
+static TilePlan plan_tiles(int n, const std::vector<vqa_op>& ops) {
+    TilePlan plan;
+    std::vector<int> todo(ops.size());
+    for (size_t i = 0; i < ops.size(); ++i) todo[i] = (int)i;
+    auto diagonal = [](int kind) { return kind == VQA_GATE_RZ || kind == VQA_GATE_Z || kind == VQA_GATE_CZ; };
+    while (!todo.empty()) {
+        // tile: the low qubits plus the first eight others that pending gates need as targets
+        std::vector<int> tile;
+        for (int q = 0; q < kTileLow; ++q) tile.push_back(q);
+        for (int gi : todo) {
+            const vqa_op& op = ops[gi];
+            if (diagonal(op.kind) || op.q0 < kTileLow) continue;
+            if (std::find(tile.begin(), tile.end(), op.q0) == tile.end()) tile.push_back(op.q0);
+            if ((int)tile.size() == kTileBits) break;
+        }
+        for (int q = kTileLow; q < n && (int)tile.size() < kTileBits; ++q)
+            if (std::find(tile.begin(), tile.end(), q) == tile.end()) tile.push_back(q);
+        std::sort(tile.begin(), tile.end());
+        TilePlan::Pass pass;
+        int pos_of[64];
+        for (int q = 0; q < 64; ++q) pos_of[q] = 32 + q;                 // outer by default
+        for (int p = 0; p < kTileBits; ++p) { pass.tq[p] = tile[p]; pos_of[tile[p]] = p; }
+        uint64_t held = 0;
+        std::vector<int> rest;
+        std::vector<TileGate> taken;
+        for (int gi : todo) {
+            const vqa_op& op = ops[gi];
+            const uint64_t qs = ((uint64_t)1 << op.q0) | (op.q1 >= 0 ? (uint64_t)1 << op.q1 : 0);
+            const bool ok = !(held & qs) && (diagonal(op.kind) || pos_of[op.q0] < 32) &&
+                            (int)taken.size() < kGateBatch;
+            if (!ok) {
+                held |= qs;
+                rest.push_back(gi);
+                continue;
+            }
+            taken.push_back(TileGate{ op.kind, pos_of[op.q0], op.q1 >= 0 ? pos_of[op.q1] : -1, gi });
+        }
+        group_segments(pass, taken);
+        todo.swap(rest);
+        plan.passes.push_back(std::move(pass));
+    }
+    for (const auto& p : plan.passes) {
+        plan.all_gates.insert(plan.all_gates.end(), p.gates.begin(), p.gates.end());
+        plan.all_segs.insert(plan.all_segs.end(), p.segs.begin(), p.segs.end());
+    }
+    return plan;
+}
+
 struct ZBatch {
     int nz;
     uint64_t z[kZBatch];
@@ -223,7 +500,7 @@ __global__ __launch_bounds__(kT) void k_finish(const double* partial, int nb, in
     }
 }
 
-int launch_gates(const EvalCall& call, const HbmCommon& h, double2* st, double2* tab) {
+int launch_gates(const EvalCall& call, const HbmCommon& h, double2* st, double2* tab, void* gate_buf) {
     const int n = h.n, C = h.C;
     const int64_t D = (int64_t)1 << n;
     const int64_t tot = D * C;
@@ -233,6 +510,47 @@ int launch_gates(const EvalCall& call, const HbmCommon& h, double2* st, double2*
     if (na > 0)
         hipLaunchKernelGGL(k_angles, dim3((unsigned)((na + kT - 1) / kT)), dim3(kT), 0, call.stream,
                            h, tab);
+    if (n >= kTileBits + 1 && call.c->engine != 4 && gate_buf != nullptr) {
+        {   // the plan lives as long as the circuit: the asynchronous copies below read its host images
+            std::lock_guard<std::mutex> lk(call.c->mu);
+            if (!call.c->hbm_plan) call.c->hbm_plan = std::make_shared<TilePlan>(plan_tiles(n, call.c->ops));
+        }
+        const TilePlan& plan = *static_cast<const TilePlan*>(call.c->hbm_plan.get());
+        TileGate* d_gates = (TileGate*)gate_buf;
+        TileSeg* d_segs = (TileSeg*)((char*)gate_buf + (size_t)std::max(h.n_ops, 1) * sizeof(TileGate));
+        if (!plan.all_gates.empty()) {
+            VQA_HIP(hipMemcpyAsync(d_gates, plan.all_gates.data(), plan.all_gates.size() * sizeof(TileGate),
+                                   hipMemcpyHostToDevice, call.stream));
+            VQA_HIP(hipMemcpyAsync(d_segs, plan.all_segs.data(), plan.all_segs.size() * sizeof(TileSeg),
+                                   hipMemcpyHostToDevice, call.stream));
+        }
+        VQA_HIP(hipFuncSetAttribute((const void*)k_tile_pass, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    kTileAmps * (int)sizeof(double2)));
+        size_t goff = 0, soff = 0;
+        for (const auto& p : plan.passes) {
+            TilePassArgs a;
+            a.n = n; a.C = C; a.n_ops = h.n_ops;
+            a.n_outer = 0;
+            for (int q = 0; q < n; ++q) {
+                bool in_tile = false;
+                for (int k = 0; k < kTileBits; ++k) in_tile |= p.tq[k] == q;
+                if (!in_tile) a.oq[a.n_outer++] = q;
+            }
+            for (int k = 0; k < kTileBits; ++k) a.tq[k] = p.tq[k];
+            a.gates = d_gates + goff;
+            a.n_gates = (int)p.gates.size();
+            a.segs = d_segs + soff;
+            a.n_segs = (int)p.segs.size();
+            a.tab = tab;
+            goff += p.gates.size();
+            soff += p.segs.size();
+            if (a.n_gates == 0) continue;
+            hipLaunchKernelGGL(k_tile_pass, dim3((unsigned)(D >> kTileBits), C), dim3(kT),
+                               kTileAmps * sizeof(double2), call.stream, st, a);
+        }
+        VQA_HIP(hipGetLastError());
+        return VQA_OK;
+    }
     for (int g = 0; g < h.n_ops; ++g) {
         const vqa_op& op = call.c->ops[g];
         if (op.kind == VQA_GATE_RZ || op.kind == VQA_GATE_Z || op.kind == VQA_GATE_CZ) {
@@ -278,13 +596,15 @@ int hbm_engine_run(const EvalCall& call) {
     Cmax = std::min<int64_t>(Cmax, call.E);
     const size_t st_bytes = (size_t)Cmax * D * sizeof(double2);
     const size_t tab_bytes = ((size_t)Cmax * std::max(call.c->n_ops, 1) * sizeof(double2) + 255) & ~(size_t)255;
-    const size_t part_bytes = (size_t)Cmax * nb * kZBatch * sizeof(double);
+    const size_t part_bytes = ((size_t)Cmax * nb * kZBatch * sizeof(double) + 255) & ~(size_t)255;
+    const size_t gate_bytes = (size_t)std::max(call.c->n_ops, 1) * (sizeof(TileGate) + sizeof(TileSeg));
     void* ws = nullptr;
-    rc = workspace_get(call.device, st_bytes + tab_bytes + part_bytes, &ws);
+    rc = workspace_get(call.device, st_bytes + tab_bytes + part_bytes + gate_bytes, &ws);
     if (rc) return rc;
     double2* st = (double2*)ws;
     double2* tab = (double2*)((char*)ws + st_bytes);
     double* partial = (double*)((char*)ws + st_bytes + tab_bytes);
+    void* gate_buf = (char*)ws + st_bytes + tab_bytes + part_bytes;
 
     const int n_obs = call.obs.n_obs;
     for (int64_t e0 = 0; e0 < call.E; e0 += Cmax) {
@@ -298,7 +618,7 @@ int hbm_engine_run(const EvalCall& call) {
         h.spec = call.spec;
         h.e_base = e0;
         h.C = (int)std::min<int64_t>(Cmax, call.E - e0);
-        rc = launch_gates(call, h, st, tab);
+        rc = launch_gates(call, h, st, tab, gate_buf);
         if (rc) return rc;
         // observables
         for (int o = 0; o < n_obs; ++o) {
@@ -364,8 +684,9 @@ int hbm_engine_statevector(const EvalCall& call, double* d_out_state) {
     const int n = call.c->n_qubits;
     if (n < 1 || n > 30) VQA_FAIL(VQA_EUNSUPPORTED, "HBM engine supports 1..30 qubits (got %d)", n);
     const size_t tab_bytes = ((size_t)std::max(call.c->n_ops, 1) * sizeof(double2) + 255) & ~(size_t)255;
+    const size_t gate_bytes = (size_t)std::max(call.c->n_ops, 1) * (sizeof(TileGate) + sizeof(TileSeg));
     void* ws = nullptr;
-    int rc = workspace_get(call.device, tab_bytes, &ws);
+    int rc = workspace_get(call.device, tab_bytes + gate_bytes, &ws);
     if (rc) return rc;
     HbmCommon h;
     h.n = n;
@@ -377,7 +698,7 @@ int hbm_engine_statevector(const EvalCall& call, double* d_out_state) {
     h.spec = call.spec;
     h.e_base = 0;
     h.C = 1;
-    return launch_gates(call, h, (double2*)d_out_state, (double2*)ws);
+    return launch_gates(call, h, (double2*)d_out_state, (double2*)ws, (char*)ws + tab_bytes);
 }
 
 }  // namespace vqa

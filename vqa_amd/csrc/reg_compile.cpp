@@ -255,11 +255,15 @@ bool reg_compile(int n, int n_theta, const std::vector<vqa_op>& gate_list, RegPr
         if (p < R) emit(ROP_UREG, p, ue);
         else emit(ROP_ULANE, p - R, ue);
     };
-    auto cheap = [&](int p) { return p < R || p == R + 0 || p == R + 1 || p == R + 3; };
+    // VQA_REG_SCHED (environment, experiments): 1 = rotate on register bits only (more
+    // transpositions, no lane rotations); default: register bits and the cheap lane bits
+    const char* sched_env = getenv("VQA_REG_SCHED");
+    const int sched = sched_env ? atoi(sched_env) : 0;
+    auto cheap = [&](int p) { return p < R || (sched == 0 && (p == R + 0 || p == R + 1 || p == R + 3)); };
     // slots a transposition may bring a qubit to: every cheap position but register bit R-1,
     // which stays where it is so that a transposition can run in two halves
-    const int n_swap_slots = 6;
-    const int cheap_slots[n_swap_slots] = { 0, 1, 2, R + 0, R + 1, R + 3 };
+    const int n_swap_slots = sched == 1 ? 3 : 6;
+    const int cheap_slots[6] = { 0, 1, 2, R + 0, R + 1, R + 3 };
 
     for (int u = 0; u < NU; ++u) {
         std::vector<std::pair<int, int>> byq;  // (position, qubit)

@@ -136,7 +136,8 @@ static int run_call(EvalCall& call, DeviceCtx* ctx) {
         if (call.spec.psr && call.n_sweep > 0 && reg_engine_can_sweep(*call.c->reg))
             return reg_engine_sweep(call, ctx->reg_prog, *call.c->reg, call.n_sweep);
         return reg_engine_run(call, ctx->reg_prog, *call.c->reg);
-    case 3: return hbm_engine_run(call);
+    case 3:
+    case 4: return hbm_engine_run(call);
     default: VQA_FAIL(VQA_EUNSUPPORTED, "engine %d is not available in this build", call.c->engine);
     }
 }
@@ -202,7 +203,7 @@ int vqa_sync(int device) {
 }
 
 int vqa_set_engine(int engine) {
-    if (engine < 0 || engine > 3) VQA_FAIL(VQA_EINVAL, "engine must be 0..3 (got %d)", engine);
+    if (engine < 0 || engine > 4) VQA_FAIL(VQA_EINVAL, "engine must be 0..4 (got %d)", engine);
     g_engine = engine;
     return VQA_OK;
 }

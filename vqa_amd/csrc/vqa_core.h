@@ -122,6 +122,7 @@ struct vqa_circuit {
     int engine;  // resolved engine: 1 LDS, 2 register-blocked, 3 HBM
     std::vector<vqa_op> ops;
     std::shared_ptr<vqa::RegProgram> reg;  // host copy of the engine-2 program (may be null)
+    std::shared_ptr<void> hbm_plan;        // engine 3: the gate list cut into tiled passes (built on first use)
     std::mutex mu;
     std::map<int, vqa::DeviceCtx> dev;
 };
