@@ -128,3 +128,28 @@ def test_pauli_sum_target_matches_oracle_circuit():
     a, b = vg.iEval(p, np.full(vg.n_params, 10)), vo.iEval(p, np.full(vo.n_params, 10))
     assert np.max(np.abs(a["grad"] - b["grad"])) < 1e-9
     assert np.max(np.abs(a["gvar_list"] - b["gvar_list"])) < 1e-8
+
+
+def test_iris_classifier_trains_on_gpu():
+    """The 4-qubit Iris configuration end to end: RY encoding, 3 layers of RY/RZ + CZ ring,
+    partial-MSE gradient with finite shots, built-in Adam; the exact error rate must not get
+    worse and the exact loss must go down."""
+    from sklearn.datasets import load_iris
+    from vqa_amd.qml_utils import create_ry_rz_cz_ansatz
+
+    data = load_iris()
+    x = (data.data - data.data.min(0)) / (data.data.max(0) - data.data.min(0)) * np.pi
+    rng = np.random.default_rng(0)
+    perm = rng.permutation(len(x))
+    tr, te = perm[:105], perm[105:]
+    c = create_ry_rz_cz_ansatz(4, 3, seed=0, circuit_cls=LearningCircuit)
+    clf = myQNN_classifier(4, c, x[tr], data.target[tr], x[te], data.target[te])
+    p0 = rng.uniform(0, 2 * np.pi, clf.n_params)
+    np.random.seed(1)
+    clf.compile(optimizer="Adam", loss="mean_squared_error", partial_MSE=True,
+                hpara=dict(LR_rule=0.1, s_list_rule=np.full(clf.n_params, 200), batch_size_rule=32), init_params=p0)
+    res = clf.fit(options=dict(max_iter=40), auto_save=False)
+    first, last = res["func_evol"][0], res["func_evol"][-1]
+    assert last["train loss"] < first["train loss"] - 0.05
+    assert last["train"] <= first["train"] + 1e-9
+    assert res["total_shots"][-1] == 40 * 32 * 200 * (2 * clf.n_params + 1)
