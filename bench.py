@@ -71,6 +71,9 @@ def main():
     ap.add_argument("--engine", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--backend", default="nccl", help="process-group backend (gloo: rehearsals of the N > 1 path)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="every rank on cuda:0 (rehearsal of the N > 1 path on a one-GPU box; not a valid number)")
     args = ap.parse_args()
 
     import torch
@@ -86,10 +89,15 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py needs a GPU: the HIP engine has no CPU fallback", file=sys.stderr)
         sys.exit(2)
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(args.backend)
 
     from vqa_amd import LearningCircuit, Observable, _lib, create_ibm_HEA_ansatz
     from vqa_amd.distributed import sharded_mse_gradient
