@@ -146,6 +146,49 @@ def test_exact_mode_gradient_is_the_mse_gradient():
         assert abs(fd - g[i]) < 1e-7
 
 
+def test_regression_class_l2_penalty():
+    """myQNNs_regression.py:1311-1320, 1352-1355, 1560-1564, 1644-1647: the standalone regressor adds
+    lmd * (params - centre) to the gradient, the centre being reg_w_coef * max|y| on the scale only
+    (its sign following the scale's when Take_abs), max(y) so far in the online variant."""
+    q, p0 = small_regressor(min_approx=-10)
+    N = len(q.x_train)
+    shots = np.full(q.n_params, 30)
+    g0 = myQNN_base.MSE_grad_eval(q, p0, shots, mini_batch_size=N)
+    q.reset_remain_ind()
+    ymax = np.max(np.abs(q.y_train))
+    assert q._max_abs_y_train == ymax
+    g1 = q.MSE_grad_eval(p0, shots, mini_batch_size=N, L2_reg_lmd=0.25)
+    cent = np.zeros_like(p0); cent[-1] = ymax
+    assert np.max(np.abs(g1 - (g0 + 0.25 * (p0 - cent)))) < 1e-13
+    pneg = p0.copy(); pneg[-1] = -0.8
+    gneg0 = myQNN_base.MSE_grad_eval(q, pneg, shots, mini_batch_size=N)
+    gneg = q.MSE_grad_eval(pneg, shots, mini_batch_size=N, L2_reg_lmd=0.25, reg_w_coef=2.0, Take_abs=True)
+    assert abs((gneg - gneg0)[-1] - 0.25 * (pneg[-1] + 2.0 * ymax)) < 1e-13
+    # online centre: the running maximum of the labels of the batches seen so far
+    q.reset_remain_ind()
+    np.random.seed(2)
+    seen = []
+    for _ in range(3):
+        g = q.MSE_grad_eval(p0, shots, mini_batch_size=4, L2_reg_lmd=1.0, Online_reg_w_center=True)
+        seen.append(np.max(q.cache_y_train_eval))
+        assert q._max_abs_y_online == max(seen)
+    # the vector-lambda form and the two other oracles
+    lam = np.linspace(0.0, 0.5, q.n_params)
+    np.random.seed(4)
+    out = q.MSE_iEval(p0, shots * 10, mini_batch_size=N, option_min_approx=0, L2_reg_lmd=lam)
+    np.random.seed(4)
+    q.reset_remain_ind()
+    ref = myQNN_base.MSE_iEval(q, p0, shots * 10, mini_batch_size=N, option_min_approx=0, second_order=False)
+    cent[-1] = 1.5 * ymax
+    assert np.max(np.abs(out["grad"] - (ref["grad"] + lam * (p0 - cent)))) < 1e-13
+    assert np.array_equal(out["gvar_list_EV"], ref["gvar_list_EV"])
+    np.random.seed(6)
+    r1 = q.MSE_iEval_iRandom(p0, np.full(q.n_params, 400), L2_reg_lmd=0.1)
+    np.random.seed(6)
+    r0 = myQNN_base.MSE_iEval_iRandom(q, p0, np.full(q.n_params, 400))
+    assert np.max(np.abs(r1["grad"] - (r0["grad"] + 0.1 * (p0 - cent)))) < 1e-13
+
+
 def test_loss_eval_and_ieval_exact_mode():
     q, p0 = small_regressor(min_approx=-10)
     N = len(q.x_train)

@@ -741,4 +741,64 @@ class myQNN_base:
 
 
 class myQNN_regression(myQNN_base):
-    """vqa/QNN/myQNNs_regression.py:256 is the same regressor kept as a standalone class."""
+    """vqa/QNN/myQNNs_regression.py:256: the regressor kept as a standalone class there.  Same
+    circuit path as myQNN_base; its gradient oracles add an L2 penalty that pulls the circuit
+    parameters to 0 and the scale parameter to `reg_w_coef * max|y|` (myQNNs_regression.py:
+    1311-1320, 1352-1355, 1560-1564, 1644-1647), and MSE_iEval defaults to first-order variance
+    terms (second_order=False, myQNNs_regression.py:1381)."""
+
+    def set_data(self, x_train, y_train, x_test, y_test):
+        super().set_data(x_train, y_train, x_test, y_test)
+        if x_train is not None and y_train is not None:
+            self._max_abs_y_train = np.max(np.abs(self.y_train))     # myQNNs_regression.py:342
+
+    def _l2_centre(self, params, y_eval, Online_reg_w_center, reg_w_coef):
+        """Centre of the penalty: zero for the circuit parameters, reg_w_coef * (largest label
+        seen so far | largest |label| of the training set) for the scale (1311-1320)."""
+        if Online_reg_w_center:
+            # the reference tracks max(y), not max|y|, in the online variant (1312-1315)
+            cur = np.max(y_eval)
+            self._max_abs_y_online = cur if not hasattr(self, "_max_abs_y_online") else max(cur, self._max_abs_y_online)
+            w_center = self._max_abs_y_online
+        else:
+            w_center = self._max_abs_y_train
+        cent = np.zeros_like(params)
+        cent[-1] = w_center * reg_w_coef
+        return cent
+
+    @staticmethod
+    def _l2_term(params, L2_reg_lmd, cent, Take_abs):
+        sign_for_w = np.full_like(params, 1.0)
+        if Take_abs:
+            sign_for_w[-1] = np.sign(params[-1])          # penalty (|w| - a)^2 on the scale
+        return L2_reg_lmd * (params - sign_for_w * cent)
+
+    def MSE_grad_eval(self, params, n_shots_list, mini_batch_size=None, option_min_approx=None, option_weight=None,
+                      L2_reg_lmd=0.0, Online_reg_w_center=False, reg_w_coef=1, Take_abs=False):
+        """myQNNs_regression.py:1293-1355."""
+        params = np.asarray(params, dtype=float)
+        grad = super().MSE_grad_eval(params, n_shots_list, mini_batch_size=mini_batch_size,
+                                     option_min_approx=option_min_approx, option_weight=option_weight)
+        cent = self._l2_centre(params, self.cache_y_train_eval, Online_reg_w_center, reg_w_coef)
+        return grad + self._l2_term(params, L2_reg_lmd, cent, Take_abs)
+
+    def MSE_iEval(self, params, n_shots_list, option_min_approx=None, option_weight=None, mini_batch_size=None,
+                  Max_n_shots0=True, second_order=False, L2_reg_lmd=0.0, Online_reg_w_center=False, reg_w_coef=1.5,
+                  WoR_correct=False, Take_abs=False):
+        """myQNNs_regression.py:1381-1571 (WoR_correct is accepted and unused there as well)."""
+        params = np.asarray(params, dtype=float)
+        out = super().MSE_iEval(params, n_shots_list, option_min_approx=option_min_approx, option_weight=option_weight,
+                                mini_batch_size=mini_batch_size, Max_n_shots0=Max_n_shots0, second_order=second_order)
+        cent = self._l2_centre(params, self.cache_y_train_eval, Online_reg_w_center, reg_w_coef)
+        out["grad"] = out["grad"] + self._l2_term(params, L2_reg_lmd, cent, Take_abs)
+        return out
+
+    def MSE_iEval_iRandom(self, params, n_shots_list, option_weight=None, L2_reg_lmd=0.0, L2_reg_cent=None,
+                          reg_w_coef=1.5, Take_abs=False):
+        """myQNNs_regression.py:1594-1648 (the L2_reg_cent argument is overwritten there, 1609-1611)."""
+        params = np.asarray(params, dtype=float)
+        out = super().MSE_iEval_iRandom(params, n_shots_list, option_weight=option_weight)
+        cent = np.zeros_like(params)
+        cent[-1] = self._max_abs_y_train * reg_w_coef
+        out["grad"] = out["grad"] + self._l2_term(params, L2_reg_lmd, cent, Take_abs)
+        return out
