@@ -305,6 +305,13 @@ struct TilePlan {
     std::vector<Pass> passes;
     std::vector<TileGate> all_gates;   // images copied to the device: the passes' gates and segments in order
     std::vector<TileSeg> all_segs;
+    std::vector<size_t> goff, soff;    // where each pass starts in the two images
+    std::vector<int> pass_of_gate;     // gate index -> the pass that runs it
+    // parameter-shift sweeps (filled by plan_sweep): the parameters that drive exactly one
+    // rotation, ordered by the pass of that rotation, and the ones that drive none
+    bool sweepable = false;
+    std::vector<int32_t> ord, ord_pass, unused;
+    std::vector<double> ord_coef;
 };
 
 static void group_segments(TilePlan::Pass& pass, const std::vector<TileGate>& in_order) {
@@ -390,11 +397,45 @@ static TilePlan plan_tiles(int n, const std::vector<vqa_op>& ops) {
         todo.swap(rest);
         plan.passes.push_back(std::move(pass));
     }
-    for (const auto& p : plan.passes) {
+    plan.pass_of_gate.assign(ops.size(), -1);
+    for (size_t k = 0; k < plan.passes.size(); ++k) {
+        const auto& p = plan.passes[k];
+        plan.goff.push_back(plan.all_gates.size());
+        plan.soff.push_back(plan.all_segs.size());
         plan.all_gates.insert(plan.all_gates.end(), p.gates.begin(), p.gates.end());
         plan.all_segs.insert(plan.all_segs.end(), p.segs.begin(), p.segs.end());
+        for (const TileGate& tg : p.gates) plan.pass_of_gate[tg.g] = (int)k;
     }
     return plan;
+}
+
+// Which parameters a sweep can serve with ONE extra state each: those that drive exactly
+// one rotation (with a non-zero coefficient).  A circuit with a parameter in several
+// gates is left to the explicit instance list.
+static void plan_sweep(TilePlan& plan, int n_theta, const std::vector<vqa_op>& ops) {
+    std::vector<int> count(n_theta, 0), gate(n_theta, -1);
+    for (size_t g = 0; g < ops.size(); ++g) {
+        const vqa_op& op = ops[g];
+        if (op.kind >= VQA_GATE_RX && op.kind <= VQA_GATE_RZ && op.src == VQA_SRC_THETA) {
+            ++count[op.idx];
+            gate[op.idx] = (int)g;
+        }
+    }
+    plan.sweepable = true;
+    std::vector<int> with;
+    for (int i = 0; i < n_theta; ++i) {
+        if (count[i] == 0) plan.unused.push_back(i);
+        else if (count[i] == 1 && ops[gate[i]].coef != 0.0) with.push_back(i);
+        else plan.sweepable = false;
+    }
+    std::stable_sort(with.begin(), with.end(), [&](int a, int b) {
+        return plan.pass_of_gate[gate[a]] < plan.pass_of_gate[gate[b]];
+    });
+    for (int i : with) {
+        plan.ord.push_back(i);
+        plan.ord_pass.push_back(plan.pass_of_gate[gate[i]]);
+        plan.ord_coef.push_back(ops[gate[i]].coef);
+    }
 }
 
 struct ZBatch {
@@ -500,6 +541,231 @@ __global__ __launch_bounds__(kT) void k_finish(const double* partial, int nb, in
     }
 }
 
+// ---- parameter-shift sweeps ---------------------------------------------------------
+// With R(a) = exp(i a/2 P):  R(a +- d) = cos(d/2) R(a) +- sin(d/2) R(a + pi), so the two
+// shifted final states of a parameter that drives one rotation are  c psi +- s phi  with
+// psi the unshifted final state, phi the final state with that angle moved by pi, and
+// (c, s) = (cos, sin)(coef * shift / 2).  For a Hermitian O
+//     E+- = c^2 <psi|O|psi> + s^2 <phi|O|phi> +- 2 c s Re <psi|O|phi>,
+// and the same holds bin by bin for the marginal.  One propagated state per parameter
+// gives both shifted values; it starts from the unshifted state in front of the pass that
+// holds the rotation, so the passes before it are shared by every parameter.
+
+// (cos, sin) of the half angles for slots [0, n_slots): slots 0 and 1 unshifted, slot 2 + s
+// has the rotation of parameter ord[s] moved by pi
+__global__ __launch_bounds__(kT) void k_sweep_angles(HbmCommon h, int64_t j, const int32_t* ord, int n_slots,
+                                                     double2* tab) {
+    const int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;
+    if (i >= (int64_t)n_slots * h.n_ops) return;
+    const int sl = (int)(i / h.n_ops), g = (int)(i - (int64_t)sl * h.n_ops);
+    const vqa_op op = h.ops[g];
+    double2 cs = make_double2(1.0, 0.0);
+    if (op.kind >= VQA_GATE_RX && op.kind <= VQA_GATE_RZ) {
+        int b = h.spec.sel ? h.spec.sel[j] : (int)j;
+        if (!(h.spec.B == 0 || (unsigned)b < (unsigned)h.spec.B)) b = 0;   // reported as NaN by the finishing kernels
+        const int sparam = sl < 2 ? -1 : ord[sl - 2];
+        const double sval = op.coef != 0.0 ? 3.14159265358979323846 / op.coef : 0.0;
+        const double ang = op_angle(op, h.theta, h.input + (size_t)b * h.n_input, sparam, sval);
+        double sn, c;
+        sincos(0.5 * ang, &sn, &c);
+        cs = make_double2(c, sn);
+    }
+    tab[i] = cs;
+}
+
+// dst[c][k] = src[k] for c < count: one read, count writes
+__global__ __launch_bounds__(kT) void k_spawn(double2* dst, const double2* src, int64_t D, int count) {
+    const int64_t k = (int64_t)blockIdx.x * kT + threadIdx.x;
+    if (k >= D) return;
+    const double2 v = src[k];
+    for (int c = 0; c < count; ++c) dst[(int64_t)c * D + k] = v;
+}
+
+// stage 1 for state pairs (psi = f, phi = slot ci): per Z-string (or marginal bin) the sums
+// of sign |phi|^2 and sign Re(conj(psi) phi); partial[((ci * nb + blk) * kZBatch + t) * 2 + {0, 1}]
+__global__ __launch_bounds__(kT) void k_zpart2(const double2* f, const double2* st, int n, ZBatch zb,
+                                               double* partial) {
+    __shared__ double red[4];
+    const int64_t D = (int64_t)1 << n;
+    const int ci = blockIdx.y, nb = gridDim.x;
+    const double2* s = st + ((int64_t)ci << n);
+    double acc[kZBatch], acx[kZBatch];
+#pragma unroll
+    for (int t = 0; t < kZBatch; ++t) { acc[t] = 0.0; acx[t] = 0.0; }
+    const int M1 = (1 << zb.marg_bits) - 1;
+    for (int64_t k = (int64_t)blockIdx.x * kT + threadIdx.x; k < D; k += (int64_t)nb * kT) {
+        const double2 v = s[k], u = f[k];
+        const double pr = v.x * v.x + v.y * v.y;
+        const double cr = u.x * v.x + u.y * v.y;
+#pragma unroll
+        for (int t = 0; t < kZBatch; ++t) {
+            if (t < zb.nz) {
+                if (zb.marg_bits > 0) {
+                    const bool in = (int)(k & M1) == zb.m0 + t;
+                    acc[t] += in ? pr : 0.0;
+                    acx[t] += in ? cr : 0.0;
+                } else {
+                    const bool neg = __popcll((uint64_t)k & zb.z[t]) & 1;
+                    acc[t] += neg ? -pr : pr;
+                    acx[t] += neg ? -cr : cr;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < kZBatch; ++t) {
+        if (t < zb.nz) {
+            const double r = block_sum(acc[t], red);
+            const double rx = block_sum(acx[t], red);
+            if (threadIdx.x == 0) {
+                double* o = &partial[(((int64_t)ci * nb + blockIdx.x) * kZBatch + t) * 2];
+                o[0] = r;
+                o[1] = rx;
+            }
+        }
+    }
+}
+
+// one Pauli string with X/Y factors for state pairs: <phi|P|phi> and Re <psi|P|phi>
+__global__ __launch_bounds__(kT) void k_xpart2(const double2* f, const double2* st, int n, uint64_t z,
+                                               uint64_t x, double* partial) {
+    __shared__ double red[4];
+    const int64_t D = (int64_t)1 << n;
+    const int ci = blockIdx.y, nb = gridDim.x;
+    const double2* s = st + ((int64_t)ci << n);
+    const int ny = __popcll(x & z) & 3;
+    double acc = 0.0, acx = 0.0;
+    for (int64_t k = (int64_t)blockIdx.x * kT + threadIdx.x; k < D; k += (int64_t)nb * kT) {
+        const double2 v = s[k], w = s[k ^ (int64_t)x], u = f[k ^ (int64_t)x];
+        const double pr = w.x * v.x + w.y * v.y, pim = w.x * v.y - w.y * v.x;
+        const double qr = u.x * v.x + u.y * v.y, qim = u.x * v.y - u.y * v.x;
+        const double val = ny == 0 ? pr : ny == 1 ? -pim : ny == 2 ? -pr : pim;
+        const double vax = ny == 0 ? qr : ny == 1 ? -qim : ny == 2 ? -qr : qim;
+        const bool neg = __popcll((uint64_t)k & z) & 1;
+        acc += neg ? -val : val;
+        acx += neg ? -vax : vax;
+    }
+    const double r = block_sum(acc, red);
+    const double rx = block_sum(acx, red);
+    if (threadIdx.x == 0) {
+        double* o = &partial[(((int64_t)ci * nb + blockIdx.x) * kZBatch) * 2];
+        o[0] = r;
+        o[1] = rx;
+    }
+}
+
+// stage 2 for state pairs: rows 2i+1 (+) and 2i+2 (-) of sample j, i = ord[ci]
+//   first flush of a column:   c^2 * (row 0 of the sample) + s^2 A +- 2 c s X
+//   later flushes:             += s^2 A +- 2 c s X
+__global__ __launch_bounds__(kT) void k_finish2(const double* partial, int nb, int nz, ZBatch zb, int use_coef,
+                                                double xcoef, double* out, int64_t row0, const int32_t* ord,
+                                                const double* ord_coef, double shift, int stride, int col0,
+                                                int spread, int accumulate) {
+    __shared__ double red[4];
+    const int ci = blockIdx.x;
+    double sn, c;
+    sincos(0.5 * ord_coef[ci] * shift, &sn, &c);
+    const int64_t rp = row0 + 2 * (int64_t)ord[ci] + 1, rm = rp + 1;
+    double ta = 0.0, tx = 0.0;
+    for (int t = 0; t < nz; ++t) {
+        double va = 0.0, vx = 0.0;
+        for (int b = threadIdx.x; b < nb; b += kT) {
+            const double* q = &partial[(((int64_t)ci * nb + b) * kZBatch + t) * 2];
+            va += q[0];
+            vx += q[1];
+        }
+        const double a = block_sum(va, red);
+        const double x = block_sum(vx, red);
+        if (threadIdx.x == 0) {
+            if (spread) {
+                const double base = c * c * out[row0 * stride + col0 + t];
+                out[rp * stride + col0 + t] = base + sn * sn * a + 2.0 * c * sn * x;
+                out[rm * stride + col0 + t] = base + sn * sn * a - 2.0 * c * sn * x;
+            } else {
+                const double cf = use_coef ? zb.coef[t] : xcoef;
+                ta += cf * a;
+                tx += cf * x;
+            }
+        }
+    }
+    if (!spread && threadIdx.x == 0) {
+        double* op = &out[rp * stride + col0];
+        double* om = &out[rm * stride + col0];
+        const double base = c * c * out[row0 * stride + col0];
+        *op = (accumulate ? *op : base) + sn * sn * ta + 2.0 * c * sn * tx;
+        *om = (accumulate ? *om : base) + sn * sn * ta - 2.0 * c * sn * tx;
+    }
+}
+
+// parameters that drive no gate: both shifted rows equal the unshifted one
+__global__ __launch_bounds__(kT) void k_copy_base(double* out, int64_t row0, const int32_t* unused, int n_unused,
+                                                  int stride) {
+    const int i = blockIdx.x * kT + threadIdx.x;
+    if (i >= n_unused * stride) return;
+    const int u = i / stride, col = i - u * stride;
+    const double v = out[row0 * stride + col];
+    const int64_t rp = row0 + 2 * (int64_t)unused[u] + 1;
+    out[rp * stride + col] = v;
+    out[(rp + 1) * stride + col] = v;
+}
+
+const TilePlan& plan_of(const EvalCall& call) {
+    std::lock_guard<std::mutex> lk(call.c->mu);
+    if (!call.c->hbm_plan) {
+        auto plan = std::make_shared<TilePlan>(plan_tiles(call.c->n_qubits, call.c->ops));
+        plan_sweep(*plan, call.c->n_theta, call.c->ops);
+        call.c->hbm_plan = plan;
+    }
+    return *static_cast<const TilePlan*>(call.c->hbm_plan.get());
+}
+
+bool tiled(const EvalCall& call) { return call.c->n_qubits >= kTileBits + 1 && call.c->engine != 4; }
+
+size_t gate_buf_bytes(const EvalCall& call) {
+    return (size_t)std::max(call.c->n_ops, 1) * (sizeof(TileGate) + sizeof(TileSeg));
+}
+
+// copies the plan's gate and segment images (the plan lives as long as the circuit, so the
+// asynchronous copies may read its host images after this returns)
+int upload_plan(const EvalCall& call, const TilePlan& plan, void* gate_buf) {
+    TileGate* d_gates = (TileGate*)gate_buf;
+    TileSeg* d_segs = (TileSeg*)((char*)gate_buf + (size_t)std::max(call.c->n_ops, 1) * sizeof(TileGate));
+    if (!plan.all_gates.empty()) {
+        VQA_HIP(hipMemcpyAsync(d_gates, plan.all_gates.data(), plan.all_gates.size() * sizeof(TileGate),
+                               hipMemcpyHostToDevice, call.stream));
+        VQA_HIP(hipMemcpyAsync(d_segs, plan.all_segs.data(), plan.all_segs.size() * sizeof(TileSeg),
+                               hipMemcpyHostToDevice, call.stream));
+    }
+    VQA_HIP(hipFuncSetAttribute((const void*)k_tile_pass, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                kTileAmps * (int)sizeof(double2)));
+    return VQA_OK;
+}
+
+// pass k of the plan on C states side by side (st, their angle tables at tab)
+void launch_pass(const EvalCall& call, const TilePlan& plan, size_t k, void* gate_buf, double2* st,
+                 const double2* tab, int C) {
+    const auto& p = plan.passes[k];
+    if (p.gates.empty() || C <= 0) return;
+    const int n = call.c->n_qubits;
+    TilePassArgs a;
+    a.n = n; a.C = C; a.n_ops = call.c->n_ops;
+    a.n_outer = 0;
+    for (int q = 0; q < n; ++q) {
+        bool in_tile = false;
+        for (int t = 0; t < kTileBits; ++t) in_tile |= p.tq[t] == q;
+        if (!in_tile) a.oq[a.n_outer++] = q;
+    }
+    for (int t = 0; t < kTileBits; ++t) a.tq[t] = p.tq[t];
+    a.gates = (TileGate*)gate_buf + plan.goff[k];
+    a.n_gates = (int)p.gates.size();
+    a.segs = (TileSeg*)((char*)gate_buf + (size_t)std::max(call.c->n_ops, 1) * sizeof(TileGate)) + plan.soff[k];
+    a.n_segs = (int)p.segs.size();
+    a.tab = tab;
+    const int64_t D = (int64_t)1 << n;
+    hipLaunchKernelGGL(k_tile_pass, dim3((unsigned)(D >> kTileBits), C), dim3(kT),
+                       kTileAmps * sizeof(double2), call.stream, st, a);
+}
+
 int launch_gates(const EvalCall& call, const HbmCommon& h, double2* st, double2* tab, void* gate_buf) {
     const int n = h.n, C = h.C;
     const int64_t D = (int64_t)1 << n;
@@ -510,44 +776,11 @@ int launch_gates(const EvalCall& call, const HbmCommon& h, double2* st, double2*
     if (na > 0)
         hipLaunchKernelGGL(k_angles, dim3((unsigned)((na + kT - 1) / kT)), dim3(kT), 0, call.stream,
                            h, tab);
-    if (n >= kTileBits + 1 && call.c->engine != 4 && gate_buf != nullptr) {
-        {   // the plan lives as long as the circuit: the asynchronous copies below read its host images
-            std::lock_guard<std::mutex> lk(call.c->mu);
-            if (!call.c->hbm_plan) call.c->hbm_plan = std::make_shared<TilePlan>(plan_tiles(n, call.c->ops));
-        }
-        const TilePlan& plan = *static_cast<const TilePlan*>(call.c->hbm_plan.get());
-        TileGate* d_gates = (TileGate*)gate_buf;
-        TileSeg* d_segs = (TileSeg*)((char*)gate_buf + (size_t)std::max(h.n_ops, 1) * sizeof(TileGate));
-        if (!plan.all_gates.empty()) {
-            VQA_HIP(hipMemcpyAsync(d_gates, plan.all_gates.data(), plan.all_gates.size() * sizeof(TileGate),
-                                   hipMemcpyHostToDevice, call.stream));
-            VQA_HIP(hipMemcpyAsync(d_segs, plan.all_segs.data(), plan.all_segs.size() * sizeof(TileSeg),
-                                   hipMemcpyHostToDevice, call.stream));
-        }
-        VQA_HIP(hipFuncSetAttribute((const void*)k_tile_pass, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    kTileAmps * (int)sizeof(double2)));
-        size_t goff = 0, soff = 0;
-        for (const auto& p : plan.passes) {
-            TilePassArgs a;
-            a.n = n; a.C = C; a.n_ops = h.n_ops;
-            a.n_outer = 0;
-            for (int q = 0; q < n; ++q) {
-                bool in_tile = false;
-                for (int k = 0; k < kTileBits; ++k) in_tile |= p.tq[k] == q;
-                if (!in_tile) a.oq[a.n_outer++] = q;
-            }
-            for (int k = 0; k < kTileBits; ++k) a.tq[k] = p.tq[k];
-            a.gates = d_gates + goff;
-            a.n_gates = (int)p.gates.size();
-            a.segs = d_segs + soff;
-            a.n_segs = (int)p.segs.size();
-            a.tab = tab;
-            goff += p.gates.size();
-            soff += p.segs.size();
-            if (a.n_gates == 0) continue;
-            hipLaunchKernelGGL(k_tile_pass, dim3((unsigned)(D >> kTileBits), C), dim3(kT),
-                               kTileAmps * sizeof(double2), call.stream, st, a);
-        }
+    if (tiled(call) && gate_buf != nullptr) {
+        const TilePlan& plan = plan_of(call);
+        int rc = upload_plan(call, plan, gate_buf);
+        if (rc) return rc;
+        for (size_t k = 0; k < plan.passes.size(); ++k) launch_pass(call, plan, k, gate_buf, st, tab, C);
         VQA_HIP(hipGetLastError());
         return VQA_OK;
     }
@@ -566,15 +799,107 @@ int launch_gates(const EvalCall& call, const HbmCommon& h, double2* st, double2*
     return VQA_OK;
 }
 
+// Observables and marginal of C states side by side -> output rows e0 .. e0 + C - 1.
+// pair == nullptr: plain expectation values (k_zpart / k_xpart / k_finish).
+// pair != nullptr: the states are the pi-moved states of a sweep, `pair` the unshifted
+// final state; writes the two shifted rows of every parameter (k_*2 kernels).
+struct PairArgs {
+    const double2* f;
+    int64_t row0;
+    const int32_t* ord;
+    const double* ord_coef;
+    double shift;
+};
+
+int measure_states(const EvalCall& call, const double2* st, int C, int64_t e0, int nb, double* partial,
+                   const PairArgs* pair) {
+    const int n = call.c->n_qubits;
+    const int n_obs = call.obs.n_obs;
+    auto zlaunch = [&](const ZBatch& zb, double* out, int stride, int col0, int spread, bool first) {
+        if (pair) {
+            hipLaunchKernelGGL(k_zpart2, dim3(nb, C), dim3(kT), 0, call.stream, pair->f, st, n, zb, partial);
+            hipLaunchKernelGGL(k_finish2, dim3(C), dim3(kT), 0, call.stream, partial, nb, zb.nz, zb, 1, 0.0, out,
+                               pair->row0, pair->ord, pair->ord_coef, pair->shift, stride, col0, spread,
+                               first ? 0 : 1);
+        } else {
+            hipLaunchKernelGGL(k_zpart, dim3(nb, C), dim3(kT), 0, call.stream, st, n, zb, partial);
+            hipLaunchKernelGGL(k_finish, dim3(C), dim3(kT), 0, call.stream, partial, nb, zb.nz, zb, 1, 0.0, out,
+                               e0, stride, col0, spread, first ? 0 : 1, call.spec);
+        }
+    };
+    for (int o = 0; o < n_obs; ++o) {
+        bool first = true;
+        ZBatch zb;
+        zb.marg_bits = 0;
+        zb.m0 = 0;
+        zb.nz = 0;
+        auto flush = [&]() {
+            if (zb.nz == 0) return;
+            zlaunch(zb, call.d_out_expect, n_obs, o, 0, first);
+            first = false;
+            zb.nz = 0;
+        };
+        for (int t = call.obs.off[o]; t < call.obs.off[o + 1]; ++t) {
+            if (call.obs.x[t] == 0) {
+                zb.z[zb.nz] = call.obs.z[t];
+                zb.coef[zb.nz] = call.obs.coef[t];
+                if (++zb.nz == kZBatch) flush();
+            }
+        }
+        flush();
+        for (int t = call.obs.off[o]; t < call.obs.off[o + 1]; ++t) {
+            if (call.obs.x[t] != 0) {
+                if (pair) {
+                    hipLaunchKernelGGL(k_xpart2, dim3(nb, C), dim3(kT), 0, call.stream, pair->f, st, n,
+                                       call.obs.z[t], call.obs.x[t], partial);
+                    hipLaunchKernelGGL(k_finish2, dim3(C), dim3(kT), 0, call.stream, partial, nb, 1, zb, 0,
+                                       call.obs.coef[t], call.d_out_expect, pair->row0, pair->ord,
+                                       pair->ord_coef, pair->shift, n_obs, o, 0, first ? 0 : 1);
+                } else {
+                    hipLaunchKernelGGL(k_xpart, dim3(nb, C), dim3(kT), 0, call.stream, st, n,
+                                       call.obs.z[t], call.obs.x[t], partial);
+                    hipLaunchKernelGGL(k_finish, dim3(C), dim3(kT), 0, call.stream, partial, nb,
+                                       1, zb, 0, call.obs.coef[t], call.d_out_expect, e0, n_obs, o,
+                                       0, first ? 0 : 1, call.spec);
+                }
+                first = false;
+            }
+        }
+        if (first) {  // observable without terms: expectation 0
+            ZBatch z0;
+            z0.nz = 0; z0.marg_bits = 0; z0.m0 = 0;
+            zlaunch(z0, call.d_out_expect, n_obs, o, 0, true);
+        }
+    }
+    if (call.n_marg_bits > 0) {
+        const int M = 1 << call.n_marg_bits;
+        for (int m0 = 0; m0 < M; m0 += kZBatch) {
+            ZBatch zb;
+            zb.marg_bits = call.n_marg_bits;
+            zb.m0 = m0;
+            zb.nz = std::min(kZBatch, M - m0);
+            if (pair) {
+                zlaunch(zb, call.d_out_marginal, M, m0, 1, true);
+            } else {
+                hipLaunchKernelGGL(k_zpart, dim3(nb, C), dim3(kT), 0, call.stream, st, n, zb, partial);
+                hipLaunchKernelGGL(k_finish, dim3(C), dim3(kT), 0, call.stream, partial, nb, zb.nz, zb, 0, 0.0,
+                                   call.d_out_marginal, e0, M, m0, 1, 0, call.spec);
+            }
+        }
+    }
+    VQA_HIP(hipGetLastError());
+    return VQA_OK;
+}
+
 }  // namespace
 
-static int chunk_plan(const EvalCall& call, int64_t& Cmax, int& nb) {
+static int chunk_plan(const EvalCall& call, double frac, size_t cap_bytes, int64_t& Cmax, int& nb) {
     const int n = call.c->n_qubits;
     const int64_t D = (int64_t)1 << n;
     size_t free_b = 0, total_b = 0;
     VQA_HIP(hipMemGetInfo(&free_b, &total_b));
-    // state chunk budget: at most 8 GiB and at most 40 % of what is free now
-    size_t budget = std::min<size_t>((size_t)8 << 30, (size_t)(0.4 * (double)free_b));
+    // state budget: a share of what is free now
+    size_t budget = std::min<size_t>(cap_bytes, (size_t)(frac * (double)free_b));
     Cmax = (int64_t)(budget / ((size_t)D * sizeof(double2)));
     if (Cmax < 1) VQA_FAIL(VQA_ENOMEM, "not enough free device memory for one %d-qubit state", n);
     Cmax = std::min<int64_t>(Cmax, 4096);
@@ -591,13 +916,13 @@ int hbm_engine_run(const EvalCall& call) {
     const int64_t D = (int64_t)1 << n;
     int64_t Cmax;
     int nb;
-    int rc = chunk_plan(call, Cmax, nb);
+    int rc = chunk_plan(call, 0.4, (size_t)8 << 30, Cmax, nb);
     if (rc) return rc;
     Cmax = std::min<int64_t>(Cmax, call.E);
     const size_t st_bytes = (size_t)Cmax * D * sizeof(double2);
     const size_t tab_bytes = ((size_t)Cmax * std::max(call.c->n_ops, 1) * sizeof(double2) + 255) & ~(size_t)255;
     const size_t part_bytes = ((size_t)Cmax * nb * kZBatch * sizeof(double) + 255) & ~(size_t)255;
-    const size_t gate_bytes = (size_t)std::max(call.c->n_ops, 1) * (sizeof(TileGate) + sizeof(TileSeg));
+    const size_t gate_bytes = gate_buf_bytes(call);
     void* ws = nullptr;
     rc = workspace_get(call.device, st_bytes + tab_bytes + part_bytes + gate_bytes, &ws);
     if (rc) return rc;
@@ -606,7 +931,6 @@ int hbm_engine_run(const EvalCall& call) {
     double* partial = (double*)((char*)ws + st_bytes + tab_bytes);
     void* gate_buf = (char*)ws + st_bytes + tab_bytes + part_bytes;
 
-    const int n_obs = call.obs.n_obs;
     for (int64_t e0 = 0; e0 < call.E; e0 += Cmax) {
         HbmCommon h;
         h.n = n;
@@ -620,63 +944,128 @@ int hbm_engine_run(const EvalCall& call) {
         h.C = (int)std::min<int64_t>(Cmax, call.E - e0);
         rc = launch_gates(call, h, st, tab, gate_buf);
         if (rc) return rc;
-        // observables
-        for (int o = 0; o < n_obs; ++o) {
-            bool first = true;
-            ZBatch zb;
-            zb.marg_bits = 0;
-            zb.m0 = 0;
-            zb.nz = 0;
-            auto flush = [&]() {
-                if (zb.nz == 0) return;
-                hipLaunchKernelGGL(k_zpart, dim3(nb, h.C), dim3(kT), 0, call.stream, st, n, zb,
-                                   partial);
-                hipLaunchKernelGGL(k_finish, dim3(h.C), dim3(kT), 0, call.stream, partial, nb,
-                                   zb.nz, zb, 1, 0.0, call.d_out_expect, e0, n_obs, o, 0,
-                                   first ? 0 : 1, call.spec);
-                first = false;
-                zb.nz = 0;
-            };
-            for (int t = call.obs.off[o]; t < call.obs.off[o + 1]; ++t) {
-                if (call.obs.x[t] == 0) {
-                    zb.z[zb.nz] = call.obs.z[t];
-                    zb.coef[zb.nz] = call.obs.coef[t];
-                    if (++zb.nz == kZBatch) flush();
-                }
-            }
-            flush();
-            for (int t = call.obs.off[o]; t < call.obs.off[o + 1]; ++t) {
-                if (call.obs.x[t] != 0) {
-                    hipLaunchKernelGGL(k_xpart, dim3(nb, h.C), dim3(kT), 0, call.stream, st, n,
-                                       call.obs.z[t], call.obs.x[t], partial);
-                    hipLaunchKernelGGL(k_finish, dim3(h.C), dim3(kT), 0, call.stream, partial, nb,
-                                       1, zb, 0, call.obs.coef[t], call.d_out_expect, e0, n_obs, o,
-                                       0, first ? 0 : 1, call.spec);
-                    first = false;
-                }
-            }
-            if (first) {  // observable without terms: expectation 0
-                ZBatch z0;
-                z0.nz = 0; z0.marg_bits = 0; z0.m0 = 0;
-                hipLaunchKernelGGL(k_finish, dim3(h.C), dim3(kT), 0, call.stream, partial, nb, 0,
-                                   z0, 1, 0.0, call.d_out_expect, e0, n_obs, o, 0, 0, call.spec);
-            }
-        }
-        if (call.n_marg_bits > 0) {
-            const int M = 1 << call.n_marg_bits;
-            for (int m0 = 0; m0 < M; m0 += kZBatch) {
-                ZBatch zb;
-                zb.marg_bits = call.n_marg_bits;
-                zb.m0 = m0;
-                zb.nz = std::min(kZBatch, M - m0);
-                hipLaunchKernelGGL(k_zpart, dim3(nb, h.C), dim3(kT), 0, call.stream, st, n, zb,
-                                   partial);
-                hipLaunchKernelGGL(k_finish, dim3(h.C), dim3(kT), 0, call.stream, partial, nb,
-                                   zb.nz, zb, 0, 0.0, call.d_out_marginal, e0, M, m0, 1, 0, call.spec);
-            }
-        }
-        VQA_HIP(hipGetLastError());
+        rc = measure_states(call, st, h.C, e0, nb, partial, nullptr);
+        if (rc) return rc;
     }
+    return VQA_OK;
+}
+
+bool hbm_engine_can_sweep(const EvalCall& call) {
+    if (!tiled(call) || !call.spec.psr || call.n_sweep <= 0 || call.c->n_theta == 0) return false;
+    return plan_of(call).sweepable;
+}
+
+// Full parameter-shift sweeps of n_samples samples (rows j * (2P+1) + k of the outputs).
+int hbm_engine_sweep(const EvalCall& call, int n_samples) {
+    const int n = call.c->n_qubits;
+    if (n > 30) VQA_FAIL(VQA_EUNSUPPORTED, "HBM engine supports 1..30 qubits (got %d)", n);
+    if (call.n_marg_bits > 10)
+        VQA_FAIL(VQA_EUNSUPPORTED, "HBM engine: n_marg_bits <= 10 (got %d)", call.n_marg_bits);
+    const TilePlan& plan = plan_of(call);
+    const int64_t D = (int64_t)1 << n;
+    const int P = call.c->n_theta, K = 2 * P + 1;
+    const int m = (int)plan.ord.size(), n_unused = (int)plan.unused.size();
+    const int n_ops = std::max(call.c->n_ops, 1);
+    int64_t Cmax;
+    int nb;
+    // slot 0: unshifted final state, slot 1: running unshifted state, slots 2..: one per parameter
+    int rc = chunk_plan(call, 0.6, (size_t)200 << 30, Cmax, nb);
+    if (rc) return rc;
+    if (Cmax < 3) VQA_FAIL(VQA_ENOMEM, "not enough free device memory for three %d-qubit states", n);
+    const int C = (int)std::min<int64_t>(Cmax - 2, std::max(m, 1));
+    auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t st_bytes = (size_t)(C + 2) * D * sizeof(double2);
+    const size_t tab_bytes = pad((size_t)(C + 2) * n_ops * sizeof(double2));
+    const size_t part_bytes = pad((size_t)C * nb * kZBatch * 2 * sizeof(double));
+    const size_t gate_bytes = pad(gate_buf_bytes(call));
+    const size_t ord_bytes = pad((size_t)std::max(m, 1) * sizeof(int32_t));
+    const size_t coef_bytes = pad((size_t)std::max(m, 1) * sizeof(double));
+    const size_t unused_bytes = pad((size_t)std::max(n_unused, 1) * sizeof(int32_t));
+    void* ws = nullptr;
+    rc = workspace_get(call.device, st_bytes + tab_bytes + part_bytes + gate_bytes + ord_bytes + coef_bytes + unused_bytes, &ws);
+    if (rc) return rc;
+    char* w = (char*)ws;
+    double2* st = (double2*)w;                 w += st_bytes;
+    double2* tab = (double2*)w;                w += tab_bytes;
+    double* partial = (double*)w;              w += part_bytes;
+    void* gate_buf = w;                        w += gate_bytes;
+    int32_t* d_ord = (int32_t*)w;              w += ord_bytes;
+    double* d_coef = (double*)w;               w += coef_bytes;
+    int32_t* d_unused = (int32_t*)w;
+    rc = upload_plan(call, plan, gate_buf);
+    if (rc) return rc;
+    if (m > 0) {
+        VQA_HIP(hipMemcpyAsync(d_ord, plan.ord.data(), (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, call.stream));
+        VQA_HIP(hipMemcpyAsync(d_coef, plan.ord_coef.data(), (size_t)m * sizeof(double), hipMemcpyHostToDevice, call.stream));
+    }
+    if (n_unused > 0)
+        VQA_HIP(hipMemcpyAsync(d_unused, plan.unused.data(), (size_t)n_unused * sizeof(int32_t), hipMemcpyHostToDevice, call.stream));
+    const size_t n_pass = plan.passes.size();
+    double2* F = st;
+    double2* R = st + D;
+    double2* S = st + 2 * D;
+    const unsigned gD = (unsigned)((D + kT - 1) / kT);
+    HbmCommon h;
+    h.n = n;
+    h.n_ops = call.c->n_ops;
+    h.n_input = call.c->n_input;
+    h.ops = call.d_ops;
+    h.theta = call.d_theta;
+    h.input = call.d_input;
+    h.spec = call.spec;
+    h.C = 1;
+    for (int64_t j = 0; j < n_samples; ++j) {
+        const int64_t row0 = j * K;
+        // the unshifted circuit: row 0 of the sample (NaN when the sample index is invalid)
+        h.e_base = row0;
+        hipLaunchKernelGGL(k_init, dim3(gD), dim3(kT), 0, call.stream, F, D, D);
+        if (h.n_ops > 0)
+            hipLaunchKernelGGL(k_angles, dim3((unsigned)((h.n_ops + kT - 1) / kT)), dim3(kT), 0, call.stream, h, tab);
+        for (size_t k = 0; k < n_pass; ++k) launch_pass(call, plan, k, gate_buf, F, tab, 1);
+        rc = measure_states(call, F, 1, row0, nb, partial, nullptr);
+        if (rc) return rc;
+        if (n_unused > 0) {
+            if (call.obs.n_obs > 0)
+                hipLaunchKernelGGL(k_copy_base, dim3((unsigned)((n_unused * call.obs.n_obs + kT - 1) / kT)), dim3(kT), 0,
+                                   call.stream, call.d_out_expect, row0, d_unused, n_unused, call.obs.n_obs);
+            if (call.n_marg_bits > 0) {
+                const int M = 1 << call.n_marg_bits;
+                hipLaunchKernelGGL(k_copy_base, dim3((unsigned)((n_unused * M + kT - 1) / kT)), dim3(kT), 0,
+                                   call.stream, call.d_out_marginal, row0, d_unused, n_unused, M);
+            }
+        }
+        if (m == 0) continue;
+        // the parameters, a chunk of slots at a time, in the order of the passes that hold their rotations
+        hipLaunchKernelGGL(k_init, dim3(gD), dim3(kT), 0, call.stream, R, D, D);
+        size_t rpass = 0;
+        for (int a = 0; a < m; a += C) {
+            const int cnt = std::min(C, m - a);
+            const size_t k0 = (size_t)plan.ord_pass[a], k1 = (size_t)plan.ord_pass[a + cnt - 1];
+            const int64_t na = (int64_t)(cnt + 2) * h.n_ops;
+            hipLaunchKernelGGL(k_sweep_angles, dim3((unsigned)((na + kT - 1) / kT)), dim3(kT), 0, call.stream, h, j,
+                               d_ord + a, cnt + 2, tab);
+            for (; rpass < k0; ++rpass) launch_pass(call, plan, rpass, gate_buf, R, tab + n_ops, 1);
+            int live = 0;
+            for (size_t k = k0; k < n_pass; ++k) {
+                int fresh = 0;
+                while (live + fresh < cnt && (size_t)plan.ord_pass[a + live + fresh] == k) ++fresh;
+                if (fresh > 0)
+                    hipLaunchKernelGGL(k_spawn, dim3(gD), dim3(kT), 0, call.stream, S + (int64_t)live * D, R, D, fresh);
+                live += fresh;
+                if (k < k1) {
+                    // the running state moves on with the chunk while later passes still take copies of it
+                    launch_pass(call, plan, k, gate_buf, R, tab + n_ops, live + 1);
+                    rpass = k + 1;
+                } else {
+                    launch_pass(call, plan, k, gate_buf, S, tab + 2 * (size_t)n_ops, live);
+                }
+            }
+            PairArgs pa = { F, row0, d_ord + a, d_coef + a, call.spec.shift };
+            rc = measure_states(call, S, cnt, 0, nb, partial, &pa);
+            if (rc) return rc;
+        }
+    }
+    VQA_HIP(hipGetLastError());
     return VQA_OK;
 }
 
@@ -684,7 +1073,7 @@ int hbm_engine_statevector(const EvalCall& call, double* d_out_state) {
     const int n = call.c->n_qubits;
     if (n < 1 || n > 30) VQA_FAIL(VQA_EUNSUPPORTED, "HBM engine supports 1..30 qubits (got %d)", n);
     const size_t tab_bytes = ((size_t)std::max(call.c->n_ops, 1) * sizeof(double2) + 255) & ~(size_t)255;
-    const size_t gate_bytes = (size_t)std::max(call.c->n_ops, 1) * (sizeof(TileGate) + sizeof(TileSeg));
+    const size_t gate_bytes = gate_buf_bytes(call);
     void* ws = nullptr;
     int rc = workspace_get(call.device, tab_bytes + gate_bytes, &ws);
     if (rc) return rc;

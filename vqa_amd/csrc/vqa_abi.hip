@@ -137,6 +137,8 @@ static int run_call(EvalCall& call, DeviceCtx* ctx) {
             return reg_engine_sweep(call, ctx->reg_prog, *call.c->reg, call.n_sweep);
         return reg_engine_run(call, ctx->reg_prog, *call.c->reg);
     case 3:
+        if (hbm_engine_can_sweep(call)) return hbm_engine_sweep(call, call.n_sweep);
+        return hbm_engine_run(call);
     case 4: return hbm_engine_run(call);
     default: VQA_FAIL(VQA_EUNSUPPORTED, "engine %d is not available in this build", call.c->engine);
     }

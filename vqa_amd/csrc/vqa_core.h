@@ -152,6 +152,8 @@ int reg_engine_run(const EvalCall& call, const void* d_prog, const RegProgram& p
 bool reg_engine_can_sweep(const RegProgram& prog);
 int reg_engine_sweep(const EvalCall& call, const void* d_prog, const RegProgram& prog, int n_samples);
 int hbm_engine_run(const EvalCall& call);
+bool hbm_engine_can_sweep(const EvalCall& call);
+int hbm_engine_sweep(const EvalCall& call, int n_samples);
 int hbm_engine_statevector(const EvalCall& call, double* d_out_state);
 
 // per-device workspace owned by the library (grown on demand, never shrunk)
