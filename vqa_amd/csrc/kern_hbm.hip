@@ -17,6 +17,11 @@
 // Replaces, per instance, LearningCircuit.run(x) + Observable expectation
 // (vqa/QNN/myQNNs_base.py:692-704, 907-914) for registers that do not fit a
 // workgroup.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <algorithm>
+
 #include "vqa_core.h"
 
 namespace vqa {
@@ -131,19 +136,35 @@ __global__ __launch_bounds__(kT) void k_diag(double2* st, int n, int C, int kind
 // ---- tiled passes -----------------------------------------------------------------
 constexpr int kTileBits = 12;                 // qubits of a tile
 constexpr int kTileAmps = 1 << kTileBits;
-constexpr int kGateBatch = 256;               // gates of a pass staged in LDS (passes are cut to fit)
+constexpr int kGateBatch = 256;               // most gates in one pass
+constexpr int kMaxMats = 96;                  // most fused 2x2s in one pass (their matrices sit in LDS)
+constexpr int kMaxOps = 128;                  // most register operations in one pass
+constexpr int kMaxSweeps = 48;                // most sweeps in one pass
 constexpr int kTileLow = 4;                   // the lowest qubits belong to every tile (256-byte runs in HBM)
+constexpr int kGroup = 4;                     // tile qubits held in a thread's registers during a sweep
 
 // one gate of a pass: positions < 32 are tile positions, 32 + q is outer qubit q, -1 unused
 struct TileGate {
     int32_t kind, p0, p1, g;                  // g = index into the angle table
 };
-// Gates of a pass are grouped into segments, each one sweep over the tile in LDS:
-// the 1-qubit gates that follow each other on one tile qubit (one fused 2x2), a run of
-// diagonal gates on any qubits (one phase per amplitude), or a single CNOT.
-enum { SEG_1Q = 0, SEG_DIAG = 1, SEG_CNOT = 2 };
-struct TileSeg {
-    int32_t type, pos, begin, count;          // gates [begin, begin + count) of the pass
+// A pass is a list of SWEEPS over the tile in LDS.  In a sweep every thread holds the 16
+// amplitudes that differ in the sweep's four group positions, applies the sweep's register
+// operations to them in order -- fused 2x2s on a group position (the product of the
+// 1-qubit gates that follow each other there) and CNOTs whose target is a group position
+// (the control may be any qubit) -- then the sweep's run of diagonal gates (one phase per
+// amplitude), and puts them back.
+enum { OP_MAT = 0, OP_CNOT = 1 };
+struct GroupOp {
+    int32_t type, slot, a, b;                 // MAT: a = matrix number; CNOT: a = control position
+};
+struct MatDesc {
+    int32_t begin, count;                     // gates [begin, begin + count) of the pass, multiplied in order
+};
+struct SweepDesc {
+    int32_t gpos[kGroup];                     // group slot -> tile position
+    int32_t tpos[kTileBits - kGroup];         // thread bit -> tile position
+    int32_t op_begin, op_count;               // register operations of the pass
+    int32_t dg_begin, dg_count, dg_cross;     // diagonal gates; the first dg_cross are CZs joining the low and high six positions
 };
 struct TilePassArgs {
     int n, C, n_ops;
@@ -151,10 +172,12 @@ struct TilePassArgs {
     int oq[32];                               // outer bit number -> qubit (ascending)
     int n_outer;
     const TileGate* gates;
-    int n_gates;
-    const TileSeg* segs;
-    int n_segs;
+    const GroupOp* ops;
+    const MatDesc* mats;
+    const SweepDesc* sweeps;
+    int n_mats, n_sweeps;
     const double2* tab;
+    int debug;                                // timing experiments only (VQA_TILE_DEBUG): 2 = no register ops, 4 = no diagonal runs
 };
 
 struct c2 {
@@ -167,124 +190,172 @@ __device__ __forceinline__ bool gate_bit(int p, int64_t base, int i) {
     return p >= 32 ? ((base >> (p - 32)) & 1) != 0 : ((i >> p) & 1) != 0;
 }
 
+// LDS slot of tile index i: the low four bits are XORed with the two nibbles above, so that
+// 16 indices that differ in one position of each residue class mod 4 land in 16 different
+// 16-byte bank groups (the sweeps choose their thread bits accordingly)
+__device__ __forceinline__ int tile_slot(int i) { return i ^ ((i >> 4) & 15) ^ ((i >> 8) & 15); }
+
+template <int J>
+__device__ __forceinline__ void apply_mat(double2 (&a)[16], const double2* __restrict__ m) {
+    const double2 m00 = m[0], m01 = m[1], m10 = m[2], m11 = m[3];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        if (r & (1 << J)) continue;
+        const double2 a0 = a[r], a1 = a[r | (1 << J)];
+        double2 r0, r1;
+        r0.x = m00.x * a0.x - m00.y * a0.y + m01.x * a1.x - m01.y * a1.y;
+        r0.y = m00.x * a0.y + m00.y * a0.x + m01.x * a1.y + m01.y * a1.x;
+        r1.x = m10.x * a0.x - m10.y * a0.y + m11.x * a1.x - m11.y * a1.y;
+        r1.y = m10.x * a0.y + m10.y * a0.x + m11.x * a1.y + m11.y * a1.x;
+        a[r] = r0;
+        a[r | (1 << J)] = r1;
+    }
+}
+
+template <int J>
+__device__ __forceinline__ void apply_cnot(double2 (&a)[16], int cpos, int64_t base, int ib, const int (&off)[16]) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        if (r & (1 << J)) continue;
+        if (gate_bit(cpos, base, ib | off[r])) {
+            const double2 t = a[r];
+            a[r] = a[r | (1 << J)];
+            a[r | (1 << J)] = t;
+        }
+    }
+}
+
 __global__ __launch_bounds__(kT) void k_tile_pass(double2* st, TilePassArgs a) {
     extern __shared__ double2 tile[];
-    __shared__ TileGate sg[kGateBatch];
-    __shared__ double2 scs[kGateBatch];
-    __shared__ TileSeg ssg[kGateBatch];
-    __shared__ double2 dtab[128];
+    __shared__ double2 smat[kMaxMats * 4];
+    __shared__ double2 dtab[2][128];
     const int tid = threadIdx.x;
     const int64_t w = blockIdx.x;             // tile number: the value of the outer bits
     const int ci = blockIdx.y;
     int64_t base = 0;
     for (int j = 0; j < a.n_outer; ++j) base |= ((w >> j) & 1) << a.oq[j];
     double2* s = st + ((int64_t)ci << a.n);
-    // the gates of the pass and their angles (fetching them one by one from global memory
-    // would put two dependent loads in front of every sweep)
-    for (int k = tid; k < a.n_gates; k += kT) {
-        const TileGate t = a.gates[k];
-        sg[k] = t;
-        scs[k] = a.tab[(int64_t)ci * a.n_ops + t.g];
+    const double2* tab = a.tab + (int64_t)ci * a.n_ops;
+    // the fused 2x2s of the pass, one thread each
+    for (int k = tid; k < a.n_mats; k += kT) {
+        const MatDesc md = a.mats[k];
+        c2 m00 = { 1, 0 }, m01 = { 0, 0 }, m10 = { 0, 0 }, m11 = { 1, 0 };
+        for (int g = md.begin; g < md.begin + md.count; ++g) {
+            const TileGate tg = a.gates[g];
+            const double2 cs = tab[tg.g];
+            const double c = cs.x, sn = cs.y;
+            const double r2 = 0.70710678118654752440;
+            c2 g00, g01, g10, g11;
+            switch (tg.kind) {
+            case VQA_GATE_H: g00 = { r2, 0 }; g01 = { r2, 0 }; g10 = { r2, 0 }; g11 = { -r2, 0 }; break;
+            case VQA_GATE_X: g00 = { 0, 0 }; g01 = { 1, 0 }; g10 = { 1, 0 }; g11 = { 0, 0 }; break;
+            case VQA_GATE_Y: g00 = { 0, 0 }; g01 = { 0, -1 }; g10 = { 0, 1 }; g11 = { 0, 0 }; break;
+            case VQA_GATE_Z: g00 = { 1, 0 }; g01 = { 0, 0 }; g10 = { 0, 0 }; g11 = { -1, 0 }; break;
+            case VQA_GATE_RX: g00 = { c, 0 }; g01 = { 0, sn }; g10 = { 0, sn }; g11 = { c, 0 }; break;
+            case VQA_GATE_RY: g00 = { c, 0 }; g01 = { sn, 0 }; g10 = { -sn, 0 }; g11 = { c, 0 }; break;
+            default: /* RZ */ g00 = { c, sn }; g01 = { 0, 0 }; g10 = { 0, 0 }; g11 = { c, -sn }; break;
+            }
+            const c2 n00 = ca(cm(g00, m00), cm(g01, m10)), n01 = ca(cm(g00, m01), cm(g01, m11));
+            const c2 n10 = ca(cm(g10, m00), cm(g11, m10)), n11 = ca(cm(g10, m01), cm(g11, m11));
+            m00 = n00; m01 = n01; m10 = n10; m11 = n11;
+        }
+        smat[4 * k + 0] = make_double2(m00.x, m00.y);
+        smat[4 * k + 1] = make_double2(m01.x, m01.y);
+        smat[4 * k + 2] = make_double2(m10.x, m10.y);
+        smat[4 * k + 3] = make_double2(m11.x, m11.y);
     }
-    for (int k = tid; k < a.n_segs; k += kT) ssg[k] = a.segs[k];
     // gather: local index l (12 bits) -> global index; the low four bits are contiguous
+    int64_t g_tid = base | (tid & ((1 << kTileLow) - 1));
+    for (int j = kTileLow; j < 8; ++j) g_tid |= (int64_t)((tid >> j) & 1) << a.tq[j];
     for (int k = 0; k < kTileAmps / kT; ++k) {
-        const int l = k * kT + tid;
-        int64_t gidx = base | (l & ((1 << kTileLow) - 1));
-        for (int j = kTileLow; j < kTileBits; ++j) gidx |= (int64_t)((l >> j) & 1) << a.tq[j];
-        tile[l] = s[gidx];
+        int64_t gidx = g_tid;
+        for (int j = 8; j < kTileBits; ++j) gidx |= (int64_t)((k >> (j - 8)) & 1) << a.tq[j];
+        tile[tile_slot(k * kT + tid)] = s[gidx];
     }
-    for (int si = 0; si < a.n_segs; ++si) {
-        __syncthreads();
-        const TileSeg sgm = ssg[si];
-        if (sgm.type == SEG_DIAG) {
+    for (int si = 0; si < a.n_sweeps; ++si) {
+        const SweepDesc& sw = a.sweeps[si];
+        const int dg_begin = sw.dg_begin, dg_count = (a.debug & 4) ? 0 : sw.dg_count, dg_cross = sw.dg_cross;
+        double2* dt = dtab[si & 1];
+        if (dg_count > 0 && tid < 128) {
             // The phase of amplitude i factors into a part from its low six tile bits (and the
             // outer bits, fixed here), a part from its high six, and the signs of the CZs that
-            // join the two halves (sgm.pos of them, first in the run).  The two 64-entry tables
-            // are built by 128 threads, then every amplitude takes one complex product.
-            if (tid < 128) {
-                const int half = tid >> 6, i = half ? (tid & 63) << 6 : (tid & 63);
-                c2 ph = { 1.0, 0.0 };
-                bool neg = false;
-                for (int g = sgm.begin + sgm.pos; g < sgm.begin + sgm.count; ++g) {
-                    const TileGate tg = sg[g];
-                    const bool hi = (tg.p0 < 32 && tg.p0 >= 6) || (tg.p1 >= 6 && tg.p1 < 32);
-                    if ((int)hi != half) continue;
-                    if (tg.kind == VQA_GATE_RZ) {
-                        const double2 cs = scs[g];
-                        ph = cm(ph, { cs.x, gate_bit(tg.p0, base, i) ? -cs.y : cs.y });
-                    } else {
-                        bool f = gate_bit(tg.p0, base, i);
-                        if (tg.kind == VQA_GATE_CZ) f = f && gate_bit(tg.p1, base, i);
-                        neg ^= f;
-                    }
+            // join the two halves (the first dg_cross gates of the run).
+            const int half = tid >> 6, i = half ? (tid & 63) << 6 : (tid & 63);
+            c2 ph = { 1.0, 0.0 };
+            bool neg = false;
+            for (int g = dg_begin + dg_cross; g < dg_begin + dg_count; ++g) {
+                const TileGate tg = a.gates[g];
+                const bool hi = (tg.p0 < 32 && tg.p0 >= 6) || (tg.p1 >= 6 && tg.p1 < 32);
+                if ((int)hi != half) continue;
+                if (tg.kind == VQA_GATE_RZ) {
+                    const double2 cs = tab[tg.g];
+                    ph = cm(ph, { cs.x, gate_bit(tg.p0, base, i) ? -cs.y : cs.y });
+                } else {
+                    bool f = gate_bit(tg.p0, base, i);
+                    if (tg.kind == VQA_GATE_CZ) f = f && gate_bit(tg.p1, base, i);
+                    neg ^= f;
                 }
-                if (neg) ph = { -ph.x, -ph.y };
-                dtab[tid] = make_double2(ph.x, ph.y);
             }
-            __syncthreads();
-            for (int k = 0; k < kTileAmps / kT; ++k) {
-                const int i = k * kT + tid;
-                const double2 lo = dtab[i & 63], hi = dtab[64 + (i >> 6)];
-                c2 ph = cm({ lo.x, lo.y }, { hi.x, hi.y });
-                bool neg = false;
-                for (int g = sgm.begin; g < sgm.begin + sgm.pos; ++g) neg ^= ((i >> sg[g].p0) & (i >> sg[g].p1) & 1) != 0;
-                if (neg) ph = { -ph.x, -ph.y };
-                const double2 v = tile[i];
-                const c2 r = cm({ v.x, v.y }, ph);
-                tile[i] = make_double2(r.x, r.y);
-            }
-        } else if (sgm.type == SEG_1Q) {
-            // product of the group's 2x2s (every thread works it out: a handful of operations)
-            c2 m00 = { 1, 0 }, m01 = { 0, 0 }, m10 = { 0, 0 }, m11 = { 1, 0 };
-            for (int g = sgm.begin; g < sgm.begin + sgm.count; ++g) {
-                const int kind = sg[g].kind;
-                const double c = scs[g].x, sn = scs[g].y;
-                const double r2 = 0.70710678118654752440;
-                c2 g00, g01, g10, g11;
-                switch (kind) {
-                case VQA_GATE_H: g00 = { r2, 0 }; g01 = { r2, 0 }; g10 = { r2, 0 }; g11 = { -r2, 0 }; break;
-                case VQA_GATE_X: g00 = { 0, 0 }; g01 = { 1, 0 }; g10 = { 1, 0 }; g11 = { 0, 0 }; break;
-                case VQA_GATE_Y: g00 = { 0, 0 }; g01 = { 0, -1 }; g10 = { 0, 1 }; g11 = { 0, 0 }; break;
-                case VQA_GATE_Z: g00 = { 1, 0 }; g01 = { 0, 0 }; g10 = { 0, 0 }; g11 = { -1, 0 }; break;
-                case VQA_GATE_RX: g00 = { c, 0 }; g01 = { 0, sn }; g10 = { 0, sn }; g11 = { c, 0 }; break;
-                case VQA_GATE_RY: g00 = { c, 0 }; g01 = { sn, 0 }; g10 = { -sn, 0 }; g11 = { c, 0 }; break;
-                default: /* RZ */ g00 = { c, sn }; g01 = { 0, 0 }; g10 = { 0, 0 }; g11 = { c, -sn }; break;
+            if (neg) ph = { -ph.x, -ph.y };
+            dt[tid] = make_double2(ph.x, ph.y);
+        }
+        __syncthreads();
+        // this thread's 16 amplitudes: thread bits on tpos, register bits on gpos
+        int ib = 0;
+#pragma unroll
+        for (int b = 0; b < kTileBits - kGroup; ++b) ib |= ((tid >> b) & 1) << sw.tpos[b];
+        int off[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            off[r] = ((r & 1) << sw.gpos[0]) | (((r >> 1) & 1) << sw.gpos[1]) | (((r >> 2) & 1) << sw.gpos[2]) |
+                     (((r >> 3) & 1) << sw.gpos[3]);
+        const int sb = tile_slot(ib);
+        double2 v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = tile[sb ^ tile_slot(off[r])];
+        for (int o = sw.op_begin; o < sw.op_begin + ((a.debug & 2) ? 0 : sw.op_count); ++o) {
+            const GroupOp op = a.ops[o];
+            if (op.type == OP_MAT) {
+                const double2* m = &smat[4 * op.a];
+                switch (op.slot) {
+                case 0: apply_mat<0>(v, m); break;
+                case 1: apply_mat<1>(v, m); break;
+                case 2: apply_mat<2>(v, m); break;
+                default: apply_mat<3>(v, m); break;
                 }
-                const c2 n00 = ca(cm(g00, m00), cm(g01, m10)), n01 = ca(cm(g00, m01), cm(g01, m11));
-                const c2 n10 = ca(cm(g10, m00), cm(g11, m10)), n11 = ca(cm(g10, m01), cm(g11, m11));
-                m00 = n00; m01 = n01; m10 = n10; m11 = n11;
-            }
-            const int p = sgm.pos, bit = 1 << p;
-            for (int k = 0; k < kTileAmps / 2 / kT; ++k) {
-                const int pi = k * kT + tid;
-                const int i0 = ((pi >> p) << (p + 1)) | (pi & (bit - 1));
-                const double2 v0 = tile[i0], v1 = tile[i0 | bit];
-                const c2 a0 = { v0.x, v0.y }, a1 = { v1.x, v1.y };
-                const c2 r0 = ca(cm(m00, a0), cm(m01, a1)), r1 = ca(cm(m10, a0), cm(m11, a1));
-                tile[i0] = make_double2(r0.x, r0.y);
-                tile[i0 | bit] = make_double2(r1.x, r1.y);
-            }
-        } else {
-            const TileGate tg = sg[sgm.begin];
-            const int p = tg.p0, bit = 1 << p;
-            for (int k = 0; k < kTileAmps / 2 / kT; ++k) {
-                const int pi = k * kT + tid;
-                const int i0 = ((pi >> p) << (p + 1)) | (pi & (bit - 1));
-                if (gate_bit(tg.p1, base, i0)) {
-                    const double2 v0 = tile[i0], v1 = tile[i0 | bit];
-                    tile[i0] = v1;
-                    tile[i0 | bit] = v0;
+            } else {
+                switch (op.slot) {
+                case 0: apply_cnot<0>(v, op.a, base, ib, off); break;
+                case 1: apply_cnot<1>(v, op.a, base, ib, off); break;
+                case 2: apply_cnot<2>(v, op.a, base, ib, off); break;
+                default: apply_cnot<3>(v, op.a, base, ib, off); break;
                 }
             }
         }
+        if (dg_count > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = ib | off[r];
+                const double2 lo = dt[i & 63], hi = dt[64 + (i >> 6)];
+                c2 ph = cm({ lo.x, lo.y }, { hi.x, hi.y });
+                bool neg = false;
+                for (int g = dg_begin; g < dg_begin + dg_cross; ++g) {
+                    const TileGate tg = a.gates[g];
+                    neg ^= ((i >> tg.p0) & (i >> tg.p1) & 1) != 0;
+                }
+                if (neg) ph = { -ph.x, -ph.y };
+                const c2 rr = cm({ v[r].x, v[r].y }, ph);
+                v[r] = make_double2(rr.x, rr.y);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tile[sb ^ tile_slot(off[r])] = v[r];
     }
     __syncthreads();
     for (int k = 0; k < kTileAmps / kT; ++k) {
-        const int l = k * kT + tid;
-        int64_t gidx = base | (l & ((1 << kTileLow) - 1));
-        for (int j = kTileLow; j < kTileBits; ++j) gidx |= (int64_t)((l >> j) & 1) << a.tq[j];
-        s[gidx] = tile[l];
+        int64_t gidx = g_tid;
+        for (int j = 8; j < kTileBits; ++j) gidx |= (int64_t)((k >> (j - 8)) & 1) << a.tq[j];
+        s[gidx] = tile[tile_slot(k * kT + tid)];
     }
 }
 
@@ -292,20 +363,26 @@ __global__ __launch_bounds__(kT) void k_tile_pass(double2* st, TilePassArgs a) {
 // the non-diagonal kinds) is a tile qubit and none of its qubits is held back by
 // an earlier gate that could not run; gates that share no qubit commute, so
 // later gates on other qubits may run ahead of a held-back one.  Inside a pass
-// the gates are grouped into segments with the same argument: a gate joins the
-// last segment that touches its qubits when that is a group it fits into (the
-// 1-qubit group of its own qubit, or, for a diagonal gate, any diagonal run at or
-// behind that point), else it opens a new one.
+// the gates are grouped into sweeps with the same argument: a gate goes into the
+// earliest sweep at or behind the last one that touches its qubits -- a 1-qubit gate or
+// CNOT into the sweep's register operations when its target is (or can become) one of the
+// sweep's four group positions and the sweep's diagonal run does not yet touch its qubits;
+// a diagonal gate into the diagonal run of the last sweep that touches its qubits.
 struct TilePlan {
     struct Pass {
         int tq[kTileBits];
-        std::vector<TileGate> gates;   // in segment order
-        std::vector<TileSeg> segs;
+        std::vector<TileGate> gates;   // matrix gate lists and diagonal runs, in the order the descriptors name them
+        std::vector<GroupOp> ops;
+        std::vector<MatDesc> mats;
+        std::vector<SweepDesc> sweeps;
     };
     std::vector<Pass> passes;
-    std::vector<TileGate> all_gates;   // images copied to the device: the passes' gates and segments in order
-    std::vector<TileSeg> all_segs;
-    std::vector<size_t> goff, soff;    // where each pass starts in the two images
+    // images copied to the device: the passes' tables one after the other
+    std::vector<TileGate> all_gates;
+    std::vector<GroupOp> all_ops;
+    std::vector<MatDesc> all_mats;
+    std::vector<SweepDesc> all_sweeps;
+    std::vector<size_t> goff, ooff, moff, soff;   // where each pass starts in the images
     std::vector<int> pass_of_gate;     // gate index -> the pass that runs it
     // parameter-shift sweeps (filled by plan_sweep): the parameters that drive exactly one
     // rotation, ordered by the pass of that rotation, and the ones that drive none
@@ -314,46 +391,108 @@ struct TilePlan {
     std::vector<double> ord_coef;
 };
 
-static void group_segments(TilePlan::Pass& pass, const std::vector<TileGate>& in_order) {
-    struct Seg { int type, pos; std::vector<TileGate> g; };
-    std::vector<Seg> segs;
-    std::map<int, int> last;   // position (tile or 32 + outer qubit) -> last segment touching it
-    auto last_of = [&](int p) { auto it = last.find(p); return it == last.end() ? -1 : it->second; };
-    int last_diag = -1;
+// false when the pass needs more descriptors than the kernel holds (the caller retries with fewer gates)
+static bool group_sweeps(TilePlan::Pass& pass, const std::vector<TileGate>& in_order) {
+    struct HOp { int type, pos, ctrl; std::vector<TileGate> gates; };
+    struct HSweep { std::vector<int> gpos; std::vector<HOp> ops; std::vector<TileGate> diag; };
+    std::vector<HSweep> sweeps;
+    std::map<int, std::pair<int, int>> last;   // position -> (sweep, 0 = register operations | 1 = diagonal run)
+    auto last_of = [&](int p) { auto it = last.find(p); return it == last.end() ? std::make_pair(-1, 0) : it->second; };
+    auto fits = [&](const HSweep& sw, int t) {
+        if (std::find(sw.gpos.begin(), sw.gpos.end(), t) != sw.gpos.end()) return true;
+        if ((int)sw.gpos.size() >= kGroup) return false;
+        int same = 0;   // at most two group positions per residue class mod 4 (see tile_slot)
+        for (int p : sw.gpos) same += (p & 3) == (t & 3);
+        return same < 2;
+    };
     for (const TileGate& tg : in_order) {
         const bool diag = tg.kind == VQA_GATE_RZ || tg.kind == VQA_GATE_Z || tg.kind == VQA_GATE_CZ;
-        const int dep = std::max(last_of(tg.p0), tg.p1 >= 0 ? last_of(tg.p1) : -1);
-        int at = -1;
-        if (tg.kind != VQA_GATE_CNOT && tg.kind != VQA_GATE_CZ && tg.p0 < 32 && dep >= 0 && dep == last_of(tg.p0) &&
-            segs[dep].type == SEG_1Q && segs[dep].pos == tg.p0) {
-            at = dep;                                             // the 2x2 group of this qubit
-        } else if (diag && last_diag >= dep && last_diag >= 0) {
-            at = last_diag;                                       // a diagonal run not in front of its dependencies
+        std::pair<int, int> dep = last_of(tg.p0);
+        if (tg.p1 >= 0) dep = std::max(dep, last_of(tg.p1));
+        bool as_op = !diag;
+        if (diag && tg.kind != VQA_GATE_CZ && tg.p0 < 32 && dep.first >= 0 && dep.second == 0) {
+            // RZ / Z straight behind a fused 2x2 of its qubit joins that product
+            const HSweep& sw = sweeps[dep.first];
+            for (auto it = sw.ops.rbegin(); it != sw.ops.rend(); ++it) {
+                if (it->pos == tg.p0 || it->ctrl == tg.p0) {
+                    as_op = it->type == OP_MAT && it->pos == tg.p0;
+                    break;
+                }
+            }
+        }
+        if (as_op) {
+            int s = dep.first < 0 ? 0 : dep.second == 0 ? dep.first : dep.first + 1;
+            while (s < (int)sweeps.size() && !fits(sweeps[s], tg.p0)) ++s;
+            if (s >= (int)sweeps.size()) { sweeps.emplace_back(); s = (int)sweeps.size() - 1; }
+            HSweep& sw = sweeps[s];
+            if (std::find(sw.gpos.begin(), sw.gpos.end(), tg.p0) == sw.gpos.end()) sw.gpos.push_back(tg.p0);
+            if (tg.kind == VQA_GATE_CNOT) {
+                sw.ops.push_back(HOp{ OP_CNOT, tg.p0, tg.p1, { tg } });
+                last[tg.p1] = std::max(last_of(tg.p1), std::make_pair(s, 0));
+            } else {
+                HOp* into = nullptr;
+                for (auto it = sw.ops.rbegin(); it != sw.ops.rend(); ++it) {
+                    if (it->pos == tg.p0 || it->ctrl == tg.p0) {
+                        if (it->type == OP_MAT && it->pos == tg.p0) into = &*it;
+                        break;
+                    }
+                }
+                if (into) into->gates.push_back(tg);
+                else sw.ops.push_back(HOp{ OP_MAT, tg.p0, -1, { tg } });
+            }
+            last[tg.p0] = std::max(last_of(tg.p0), std::make_pair(s, 0));
         } else {
-            Seg sg;
-            sg.type = tg.kind == VQA_GATE_CNOT ? SEG_CNOT : diag ? SEG_DIAG : SEG_1Q;
-            sg.pos = tg.p0;
-            segs.push_back(sg);
-            at = (int)segs.size() - 1;
-            if (diag) last_diag = at;
+            int s = std::max(dep.first, 0);
+            if (sweeps.empty()) sweeps.emplace_back();
+            sweeps[s].diag.push_back(tg);
+            last[tg.p0] = std::max(last_of(tg.p0), std::make_pair(s, 1));
+            if (tg.p1 >= 0) last[tg.p1] = std::max(last_of(tg.p1), std::make_pair(s, 1));
         }
-        segs[at].g.push_back(tg);
-        last[tg.p0] = std::max(last_of(tg.p0), at);
-        if (tg.p1 >= 0) last[tg.p1] = std::max(last_of(tg.p1), at);
     }
-    for (Seg& sg : segs) {
-        int pos = sg.pos;
-        if (sg.type == SEG_DIAG) {
-            // CZs between the low six and the high six tile bits go first; pos = how many
-            auto cross = [](const TileGate& t) {
-                return t.kind == VQA_GATE_CZ && t.p0 < 32 && t.p1 < 32 && (t.p0 < 6) != (t.p1 < 6);
-            };
-            std::stable_partition(sg.g.begin(), sg.g.end(), cross);
-            pos = (int)std::count_if(sg.g.begin(), sg.g.end(), cross);
+    if ((int)sweeps.size() > kMaxSweeps) return false;
+    for (HSweep& hs : sweeps) {
+        SweepDesc sd;
+        // fill the group with unused positions, then hand out the thread bits: bits 0..3 get one
+        // position of each residue class mod 4 (classes 0, 1, 2 first), the rest ascending
+        for (int p = kTileBits - 1; p >= 0 && (int)hs.gpos.size() < kGroup; --p)
+            if (fits(hs, p) && std::find(hs.gpos.begin(), hs.gpos.end(), p) == hs.gpos.end()) hs.gpos.push_back(p);
+        std::vector<int> rest;
+        for (int p = 0; p < kTileBits; ++p)
+            if (std::find(hs.gpos.begin(), hs.gpos.end(), p) == hs.gpos.end()) rest.push_back(p);
+        std::vector<int> tp;
+        for (int cls = 0; cls < 4; ++cls) {
+            auto it = std::find_if(rest.begin(), rest.end(), [&](int p) { return (p & 3) == cls; });
+            tp.push_back(*it);   // every class keeps a position outside the group (fits())
+            rest.erase(it);
         }
-        pass.segs.push_back(TileSeg{ sg.type, pos, (int)pass.gates.size(), (int)sg.g.size() });
-        pass.gates.insert(pass.gates.end(), sg.g.begin(), sg.g.end());
+        tp.insert(tp.end(), rest.begin(), rest.end());
+        for (int j = 0; j < kGroup; ++j) sd.gpos[j] = hs.gpos[j];
+        for (int b = 0; b < kTileBits - kGroup; ++b) sd.tpos[b] = tp[b];
+        sd.op_begin = (int)pass.ops.size();
+        for (const HOp& op : hs.ops) {
+            const int slot = (int)(std::find(hs.gpos.begin(), hs.gpos.end(), op.pos) - hs.gpos.begin());
+            if (op.type == OP_MAT) {
+                pass.ops.push_back(GroupOp{ OP_MAT, slot, (int)pass.mats.size(), 0 });
+                pass.mats.push_back(MatDesc{ (int)pass.gates.size(), (int)op.gates.size() });
+                pass.gates.insert(pass.gates.end(), op.gates.begin(), op.gates.end());
+            } else {
+                pass.ops.push_back(GroupOp{ OP_CNOT, slot, op.ctrl, 0 });
+                pass.gates.push_back(op.gates[0]);   // kept for the gate -> pass map
+            }
+        }
+        sd.op_count = (int)pass.ops.size() - sd.op_begin;
+        // CZs between the low six and the high six tile bits go first
+        auto cross = [](const TileGate& t) {
+            return t.kind == VQA_GATE_CZ && t.p0 < 32 && t.p1 < 32 && (t.p0 < 6) != (t.p1 < 6);
+        };
+        std::stable_partition(hs.diag.begin(), hs.diag.end(), cross);
+        sd.dg_begin = (int)pass.gates.size();
+        sd.dg_count = (int)hs.diag.size();
+        sd.dg_cross = (int)std::count_if(hs.diag.begin(), hs.diag.end(), cross);
+        pass.gates.insert(pass.gates.end(), hs.diag.begin(), hs.diag.end());
+        pass.sweeps.push_back(sd);
     }
+    return (int)pass.mats.size() <= kMaxMats && (int)pass.ops.size() <= kMaxOps;
 }
 
 static TilePlan plan_tiles(int n, const std::vector<vqa_op>& ops) {
@@ -374,36 +513,44 @@ static TilePlan plan_tiles(int n, const std::vector<vqa_op>& ops) {
         for (int q = kTileLow; q < n && (int)tile.size() < kTileBits; ++q)
             if (std::find(tile.begin(), tile.end(), q) == tile.end()) tile.push_back(q);
         std::sort(tile.begin(), tile.end());
-        TilePlan::Pass pass;
         int pos_of[64];
         for (int q = 0; q < 64; ++q) pos_of[q] = 32 + q;                 // outer by default
-        for (int p = 0; p < kTileBits; ++p) { pass.tq[p] = tile[p]; pos_of[tile[p]] = p; }
-        uint64_t held = 0;
-        std::vector<int> rest;
-        std::vector<TileGate> taken;
-        for (int gi : todo) {
-            const vqa_op& op = ops[gi];
-            const uint64_t qs = ((uint64_t)1 << op.q0) | (op.q1 >= 0 ? (uint64_t)1 << op.q1 : 0);
-            const bool ok = !(held & qs) && (diagonal(op.kind) || pos_of[op.q0] < 32) &&
-                            (int)taken.size() < kGateBatch;
-            if (!ok) {
-                held |= qs;
-                rest.push_back(gi);
-                continue;
+        for (int p = 0; p < kTileBits; ++p) pos_of[tile[p]] = p;
+        for (int cap = kGateBatch;; cap /= 2) {
+            TilePlan::Pass pass;
+            for (int p = 0; p < kTileBits; ++p) pass.tq[p] = tile[p];
+            uint64_t held = 0;
+            std::vector<int> rest;
+            std::vector<TileGate> taken;
+            for (int gi : todo) {
+                const vqa_op& op = ops[gi];
+                const uint64_t qs = ((uint64_t)1 << op.q0) | (op.q1 >= 0 ? (uint64_t)1 << op.q1 : 0);
+                const bool ok = !(held & qs) && (diagonal(op.kind) || pos_of[op.q0] < 32) &&
+                                (int)taken.size() < cap;
+                if (!ok) {
+                    held |= qs;
+                    rest.push_back(gi);
+                    continue;
+                }
+                taken.push_back(TileGate{ op.kind, pos_of[op.q0], op.q1 >= 0 ? pos_of[op.q1] : -1, gi });
             }
-            taken.push_back(TileGate{ op.kind, pos_of[op.q0], op.q1 >= 0 ? pos_of[op.q1] : -1, gi });
+            if (!group_sweeps(pass, taken) && cap > 1) continue;
+            todo.swap(rest);
+            plan.passes.push_back(std::move(pass));
+            break;
         }
-        group_segments(pass, taken);
-        todo.swap(rest);
-        plan.passes.push_back(std::move(pass));
     }
     plan.pass_of_gate.assign(ops.size(), -1);
     for (size_t k = 0; k < plan.passes.size(); ++k) {
         const auto& p = plan.passes[k];
         plan.goff.push_back(plan.all_gates.size());
-        plan.soff.push_back(plan.all_segs.size());
+        plan.ooff.push_back(plan.all_ops.size());
+        plan.moff.push_back(plan.all_mats.size());
+        plan.soff.push_back(plan.all_sweeps.size());
         plan.all_gates.insert(plan.all_gates.end(), p.gates.begin(), p.gates.end());
-        plan.all_segs.insert(plan.all_segs.end(), p.segs.begin(), p.segs.end());
+        plan.all_ops.insert(plan.all_ops.end(), p.ops.begin(), p.ops.end());
+        plan.all_mats.insert(plan.all_mats.end(), p.mats.begin(), p.mats.end());
+        plan.all_sweeps.insert(plan.all_sweeps.end(), p.sweeps.begin(), p.sweeps.end());
         for (const TileGate& tg : p.gates) plan.pass_of_gate[tg.g] = (int)k;
     }
     return plan;
@@ -714,6 +861,16 @@ const TilePlan& plan_of(const EvalCall& call) {
     if (!call.c->hbm_plan) {
         auto plan = std::make_shared<TilePlan>(plan_tiles(call.c->n_qubits, call.c->ops));
         plan_sweep(*plan, call.c->n_theta, call.c->ops);
+        if (getenv("VQA_PLAN_DEBUG")) {
+            fprintf(stderr, "[vqa] tiled plan: %zu passes for %zu gates\n", plan->passes.size(), call.c->ops.size());
+            for (size_t k = 0; k < plan->passes.size(); ++k) {
+                const auto& p = plan->passes[k];
+                size_t nd = 0;
+                for (const auto& sd : p.sweeps) nd += sd.dg_count > 0;
+                fprintf(stderr, "[vqa]   pass %2zu: %3zu gates, %2zu sweeps (%zu with a diagonal run), %2zu fused 2x2, %3zu register ops\n",
+                        k, p.gates.size(), p.sweeps.size(), nd, p.mats.size(), p.ops.size());
+            }
+        }
         call.c->hbm_plan = plan;
     }
     return *static_cast<const TilePlan*>(call.c->hbm_plan.get());
@@ -721,21 +878,48 @@ const TilePlan& plan_of(const EvalCall& call) {
 
 bool tiled(const EvalCall& call) { return call.c->n_qubits >= kTileBits + 1 && call.c->engine != 4; }
 
+// device images of the plan: gates | ops | mats | sweeps, each sized for the whole circuit
+struct PlanImage {
+    TileGate* gates;
+    GroupOp* ops;
+    MatDesc* mats;
+    SweepDesc* sweeps;
+};
+static size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
+
 size_t gate_buf_bytes(const EvalCall& call) {
-    return (size_t)std::max(call.c->n_ops, 1) * (sizeof(TileGate) + sizeof(TileSeg));
+    const size_t g = (size_t)std::max(call.c->n_ops, 1);
+    return pad256(g * sizeof(TileGate)) + pad256(g * sizeof(GroupOp)) + pad256(g * sizeof(MatDesc)) +
+           pad256(g * sizeof(SweepDesc));
 }
 
-// copies the plan's gate and segment images (the plan lives as long as the circuit, so the
-// asynchronous copies may read its host images after this returns)
+PlanImage plan_image(const EvalCall& call, void* gate_buf) {
+    const size_t g = (size_t)std::max(call.c->n_ops, 1);
+    char* w = (char*)gate_buf;
+    PlanImage im;
+    im.gates = (TileGate*)w;   w += pad256(g * sizeof(TileGate));
+    im.ops = (GroupOp*)w;      w += pad256(g * sizeof(GroupOp));
+    im.mats = (MatDesc*)w;     w += pad256(g * sizeof(MatDesc));
+    im.sweeps = (SweepDesc*)w;
+    return im;
+}
+
+// copies the plan's tables (the plan lives as long as the circuit, so the asynchronous
+// copies may read its host images after this returns)
 int upload_plan(const EvalCall& call, const TilePlan& plan, void* gate_buf) {
-    TileGate* d_gates = (TileGate*)gate_buf;
-    TileSeg* d_segs = (TileSeg*)((char*)gate_buf + (size_t)std::max(call.c->n_ops, 1) * sizeof(TileGate));
-    if (!plan.all_gates.empty()) {
-        VQA_HIP(hipMemcpyAsync(d_gates, plan.all_gates.data(), plan.all_gates.size() * sizeof(TileGate),
+    const PlanImage im = plan_image(call, gate_buf);
+    if (!plan.all_gates.empty())
+        VQA_HIP(hipMemcpyAsync(im.gates, plan.all_gates.data(), plan.all_gates.size() * sizeof(TileGate),
                                hipMemcpyHostToDevice, call.stream));
-        VQA_HIP(hipMemcpyAsync(d_segs, plan.all_segs.data(), plan.all_segs.size() * sizeof(TileSeg),
+    if (!plan.all_ops.empty())
+        VQA_HIP(hipMemcpyAsync(im.ops, plan.all_ops.data(), plan.all_ops.size() * sizeof(GroupOp),
                                hipMemcpyHostToDevice, call.stream));
-    }
+    if (!plan.all_mats.empty())
+        VQA_HIP(hipMemcpyAsync(im.mats, plan.all_mats.data(), plan.all_mats.size() * sizeof(MatDesc),
+                               hipMemcpyHostToDevice, call.stream));
+    if (!plan.all_sweeps.empty())
+        VQA_HIP(hipMemcpyAsync(im.sweeps, plan.all_sweeps.data(), plan.all_sweeps.size() * sizeof(SweepDesc),
+                               hipMemcpyHostToDevice, call.stream));
     VQA_HIP(hipFuncSetAttribute((const void*)k_tile_pass, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 kTileAmps * (int)sizeof(double2)));
     return VQA_OK;
@@ -747,6 +931,7 @@ void launch_pass(const EvalCall& call, const TilePlan& plan, size_t k, void* gat
     const auto& p = plan.passes[k];
     if (p.gates.empty() || C <= 0) return;
     const int n = call.c->n_qubits;
+    const PlanImage im = plan_image(call, gate_buf);
     TilePassArgs a;
     a.n = n; a.C = C; a.n_ops = call.c->n_ops;
     a.n_outer = 0;
@@ -756,11 +941,16 @@ void launch_pass(const EvalCall& call, const TilePlan& plan, size_t k, void* gat
         if (!in_tile) a.oq[a.n_outer++] = q;
     }
     for (int t = 0; t < kTileBits; ++t) a.tq[t] = p.tq[t];
-    a.gates = (TileGate*)gate_buf + plan.goff[k];
-    a.n_gates = (int)p.gates.size();
-    a.segs = (TileSeg*)((char*)gate_buf + (size_t)std::max(call.c->n_ops, 1) * sizeof(TileGate)) + plan.soff[k];
-    a.n_segs = (int)p.segs.size();
+    a.gates = im.gates + plan.goff[k];
+    a.ops = im.ops + plan.ooff[k];
+    a.mats = im.mats + plan.moff[k];
+    a.sweeps = im.sweeps + plan.soff[k];
+    a.n_mats = (int)p.mats.size();
+    a.n_sweeps = (int)p.sweeps.size();
     a.tab = tab;
+    static const int dbg = getenv("VQA_TILE_DEBUG") ? atoi(getenv("VQA_TILE_DEBUG")) : 0;
+    a.debug = dbg;
+    if (dbg & 1) a.n_sweeps = 0;              // gather and scatter only
     const int64_t D = (int64_t)1 << n;
     hipLaunchKernelGGL(k_tile_pass, dim3((unsigned)(D >> kTileBits), C), dim3(kT),
                        kTileAmps * sizeof(double2), call.stream, st, a);
