@@ -19,10 +19,18 @@
 // workgroup.
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 
 #include "vqa_core.h"
+
+#ifndef VQA_TILE_GROUP
+#define VQA_TILE_GROUP 4
+#endif
+#ifndef VQA_TILES_PER_WG
+#define VQA_TILES_PER_WG 1
+#endif
 
 namespace vqa {
 
@@ -136,48 +144,62 @@ __global__ __launch_bounds__(kT) void k_diag(double2* st, int n, int C, int kind
 // ---- tiled passes -----------------------------------------------------------------
 constexpr int kTileBits = 12;                 // qubits of a tile
 constexpr int kTileAmps = 1 << kTileBits;
-constexpr int kGateBatch = 256;               // most gates in one pass
-constexpr int kMaxMats = 96;                  // most fused 2x2s in one pass (their matrices sit in LDS)
-constexpr int kMaxOps = 128;                  // most register operations in one pass
-constexpr int kMaxSweeps = 48;                // most sweeps in one pass
 constexpr int kTileLow = 4;                   // the lowest qubits belong to every tile (256-byte runs in HBM)
-constexpr int kGroup = 4;                     // tile qubits held in a thread's registers during a sweep
+constexpr int kGroup = VQA_TILE_GROUP;        // tile qubits held in a thread's registers during a sweep
+constexpr int kTT = kTileAmps >> kGroup;      // threads of a tile workgroup
+constexpr int kTA = 1 << kGroup;              // amplitudes per thread
+constexpr int kThreadBits = kTileBits - kGroup;
+constexpr int kTileWaves = 2 * (kTT / 64) / 4; // waves per SIMD with two workgroups on a CU (what their LDS allows)
+constexpr int kGateBatch = 256;               // most gates in one pass
+constexpr int kMaxMats = 48;                  // most fused 2x2s in one pass (their matrices sit in LDS)
+constexpr int kMaxOps = 96;                   // most register operations in one pass
+constexpr int kMaxSweeps = 24;                // most sweeps in one pass
+constexpr int kMaxPhaseGates = 64;            // most diagonal gates in the pass's phase-table runs
+constexpr int kMaxDiagGates = 128;            // most diagonal gates in the pass's runs of both kinds
+constexpr int kMaxShifts = 4;                 // most distinct CZ distances in a signs-only run
+constexpr int kTilesPerWg = VQA_TILES_PER_WG;  // most tiles one workgroup runs one after the other
+constexpr int kGateZZ = 9;                    // internal: CNOT(c,t) RZ_t(a) CNOT(c,t) = exp(i a/2 Z_c Z_t), p0 = t, p1 = c
 
 // one gate of a pass: positions < 32 are tile positions, 32 + q is outer qubit q, -1 unused
 struct TileGate {
     int32_t kind, p0, p1, g;                  // g = index into the angle table
 };
-// A pass is a list of SWEEPS over the tile in LDS.  In a sweep every thread holds the 16
-// amplitudes that differ in the sweep's four group positions, applies the sweep's register
+// A pass is a list of SWEEPS over the tile in LDS.  In a sweep every thread holds the
+// amplitudes that differ in the sweep's group positions, applies the sweep's register
 // operations to them in order -- fused 2x2s on a group position (the product of the
 // 1-qubit gates that follow each other there) and CNOTs whose target is a group position
-// (the control may be any qubit) -- then the sweep's run of diagonal gates (one phase per
-// amplitude), and puts them back.
+// (the control may be any qubit) -- then the sweep's run of diagonal gates, and puts them
+// back.  A diagonal run is either a phase per amplitude (two 64-entry tables for the low
+// and the high six tile positions, plus the gates that join the halves) or, when it holds
+// only Z and CZ, a sign per amplitude from a few bit masks.
 enum { OP_MAT = 0, OP_CNOT = 1 };
+enum { DG_NONE = 0, DG_PHASE = 1, DG_SIGN = 2 };
 struct GroupOp {
-    int32_t type, slot, a, b;                 // MAT: a = matrix number; CNOT: a = control position
+    int32_t type, slot, a, b;                 // MAT: a = matrix number within the pass; CNOT: a = control position
 };
 struct MatDesc {
-    int32_t begin, count;                     // gates [begin, begin + count) of the pass, multiplied in order
+    int32_t begin, count;                     // gates [begin, begin + count) of the circuit's gate image, multiplied in order
 };
 struct SweepDesc {
-    int32_t gpos[kGroup];                     // group slot -> tile position
-    int32_t tpos[kTileBits - kGroup];         // thread bit -> tile position
+    int32_t gpos[4];                          // group slot -> tile position
+    int32_t tpos[kTileBits];                  // thread bit -> tile position
     int32_t op_begin, op_count;               // register operations of the pass
-    int32_t dg_begin, dg_count, dg_cross;     // diagonal gates; the first dg_cross are CZs joining the low and high six positions
+    int32_t dg_mode, dg_begin, dg_count, dg_cross;   // DG_PHASE: gates of the phase list, the first dg_cross join the halves;
+                                                     // DG_SIGN: gates of the pass
+    int32_t n_shift, shift[kMaxShifts];       // DG_SIGN: the distances |p0 - p1| of its CZs inside the tile
+};
+struct SignRun {                              // a signs-only run with this workgroup's outer bits folded in
+    int32_t zmask, neg0, m[kMaxShifts];
 };
 struct TilePassArgs {
-    int n, C, n_ops;
+    int n, n_ops;
     int tq[kTileBits];                        // tile position -> qubit (ascending)
     int oq[32];                               // outer bit number -> qubit (ascending)
     int n_outer;
-    const TileGate* gates;
-    const GroupOp* ops;
-    const MatDesc* mats;
-    const SweepDesc* sweeps;
-    int n_mats, n_sweeps;
-    const double2* tab;
-    int debug;                                // timing experiments only (VQA_TILE_DEBUG): 2 = no register ops, 4 = no diagonal runs
+    int n_mats, n_pops, n_sweeps;             // this pass
+    int pg_begin, pg_count, dg_total;         // its diagonal gates: [pg_begin, +dg_total), the first pg_count in phase-table runs
+    int tiles_per_wg;
+    int mat_off, n_mats_total;                // where its matrices start in an instance's row of the matrix table
 };
 
 struct c2 {
@@ -189,17 +211,52 @@ __device__ __forceinline__ c2 ca(c2 a, c2 b) { return { a.x + b.x, a.y + b.y }; 
 __device__ __forceinline__ bool gate_bit(int p, int64_t base, int i) {
     return p >= 32 ? ((base >> (p - 32)) & 1) != 0 : ((i >> p) & 1) != 0;
 }
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // LDS slot of tile index i: the low four bits are XORed with the two nibbles above, so that
 // 16 indices that differ in one position of each residue class mod 4 land in 16 different
 // 16-byte bank groups (the sweeps choose their thread bits accordingly)
 __device__ __forceinline__ int tile_slot(int i) { return i ^ ((i >> 4) & 15) ^ ((i >> 8) & 15); }
 
+// the product of the 1-qubit gates [begin, begin + count) for every instance: mats[(ci * M + m) * 4 ..]
+__global__ __launch_bounds__(kT) void k_mats(const TileGate* __restrict__ gates, const MatDesc* __restrict__ descs, int M,
+                                             const double2* __restrict__ tab, int n_ops, int C, double2* __restrict__ mats) {
+    const int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;
+    if (i >= (int64_t)C * M) return;
+    const int ci = (int)(i / M), k = (int)(i - (int64_t)ci * M);
+    const MatDesc md = descs[k];
+    c2 m00 = { 1, 0 }, m01 = { 0, 0 }, m10 = { 0, 0 }, m11 = { 1, 0 };
+    for (int g = md.begin; g < md.begin + md.count; ++g) {
+        const TileGate tg = gates[g];
+        const double2 cs = tab[(int64_t)ci * n_ops + tg.g];
+        const double c = cs.x, sn = cs.y;
+        const double r2 = 0.70710678118654752440;
+        c2 g00, g01, g10, g11;
+        switch (tg.kind) {
+        case VQA_GATE_H: g00 = { r2, 0 }; g01 = { r2, 0 }; g10 = { r2, 0 }; g11 = { -r2, 0 }; break;
+        case VQA_GATE_X: g00 = { 0, 0 }; g01 = { 1, 0 }; g10 = { 1, 0 }; g11 = { 0, 0 }; break;
+        case VQA_GATE_Y: g00 = { 0, 0 }; g01 = { 0, -1 }; g10 = { 0, 1 }; g11 = { 0, 0 }; break;
+        case VQA_GATE_Z: g00 = { 1, 0 }; g01 = { 0, 0 }; g10 = { 0, 0 }; g11 = { -1, 0 }; break;
+        case VQA_GATE_RX: g00 = { c, 0 }; g01 = { 0, sn }; g10 = { 0, sn }; g11 = { c, 0 }; break;
+        case VQA_GATE_RY: g00 = { c, 0 }; g01 = { sn, 0 }; g10 = { -sn, 0 }; g11 = { c, 0 }; break;
+        default: /* RZ */ g00 = { c, sn }; g01 = { 0, 0 }; g10 = { 0, 0 }; g11 = { c, -sn }; break;
+        }
+        const c2 n00 = ca(cm(g00, m00), cm(g01, m10)), n01 = ca(cm(g00, m01), cm(g01, m11));
+        const c2 n10 = ca(cm(g10, m00), cm(g11, m10)), n11 = ca(cm(g10, m01), cm(g11, m11));
+        m00 = n00; m01 = n01; m10 = n10; m11 = n11;
+    }
+    double2* o = mats + i * 4;
+    o[0] = make_double2(m00.x, m00.y);
+    o[1] = make_double2(m01.x, m01.y);
+    o[2] = make_double2(m10.x, m10.y);
+    o[3] = make_double2(m11.x, m11.y);
+}
+
 template <int J>
-__device__ __forceinline__ void apply_mat(double2 (&a)[16], const double2* __restrict__ m) {
+__device__ __forceinline__ void apply_mat(double2 (&a)[kTA], const double2* m) {
     const double2 m00 = m[0], m01 = m[1], m10 = m[2], m11 = m[3];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int r = 0; r < kTA; ++r) {
         if (r & (1 << J)) continue;
         const double2 a0 = a[r], a1 = a[r | (1 << J)];
         double2 r0, r1;
@@ -209,13 +266,15 @@ __device__ __forceinline__ void apply_mat(double2 (&a)[16], const double2* __res
         r1.y = m10.x * a0.y + m10.y * a0.x + m11.x * a1.y + m11.y * a1.x;
         a[r] = r0;
         a[r | (1 << J)] = r1;
+        // two pairs at a time: all of them at once would double the live registers
+        if (kTA > 8 && (r & ((2 << J) | 1 | (J == 0 ? 2 : 0))) != 0) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
 template <int J>
-__device__ __forceinline__ void apply_cnot(double2 (&a)[16], int cpos, int64_t base, int ib, const int (&off)[16]) {
+__device__ __forceinline__ void apply_cnot(double2 (&a)[kTA], int cpos, int64_t base, int ib, const int (&off)[kTA]) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int r = 0; r < kTA; ++r) {
         if (r & (1 << J)) continue;
         if (gate_bit(cpos, base, ib | off[r])) {
             const double2 t = a[r];
@@ -225,162 +284,261 @@ __device__ __forceinline__ void apply_cnot(double2 (&a)[16], int cpos, int64_t b
     }
 }
 
-__global__ __launch_bounds__(kT) void k_tile_pass(double2* st, TilePassArgs a) {
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every
+// outstanding global load, which would stall the sweeps on the prefetch of the next tile.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// the outer bits of tile number w
+__device__ __forceinline__ uint32_t tile_base(const TilePassArgs& a, uint32_t w) {
+    uint32_t base = 0;
+    for (int j = 0; j < a.n_outer; ++j) base |= ((w >> j) & 1u) << a.oq[j];
+    return base;
+}
+
+// One workgroup runs the pass on `tiles_per_wg` tiles of one instance, one after the other:
+// the next tile's amplitudes are fetched from HBM while the sweeps of the current one run.
+__global__ __launch_bounds__(kTT, kTileWaves) void k_tile_pass(double2* __restrict__ st, const TileGate* __restrict__ gates,
+                                                   const GroupOp* __restrict__ ops, const SweepDesc* __restrict__ sweeps,
+                                                   const double2* __restrict__ tab, const double2* __restrict__ mats,
+                                                   TilePassArgs a) {
     extern __shared__ double2 tile[];
     __shared__ double2 smat[kMaxMats * 4];
     __shared__ double2 dtab[2][128];
+    __shared__ GroupOp s_ops[kMaxOps];
+    __shared__ SweepDesc s_sw[kMaxSweeps];
+    __shared__ SignRun s_sign[kMaxSweeps];
+    __shared__ TileGate s_dg[kMaxDiagGates];
+    __shared__ double2 s_dcs[kMaxPhaseGates];
     const int tid = threadIdx.x;
-    const int64_t w = blockIdx.x;             // tile number: the value of the outer bits
     const int ci = blockIdx.y;
-    int64_t base = 0;
-    for (int j = 0; j < a.n_outer; ++j) base |= ((w >> j) & 1) << a.oq[j];
     double2* s = st + ((int64_t)ci << a.n);
-    const double2* tab = a.tab + (int64_t)ci * a.n_ops;
-    // the fused 2x2s of the pass, one thread each
-    for (int k = tid; k < a.n_mats; k += kT) {
-        const MatDesc md = a.mats[k];
-        c2 m00 = { 1, 0 }, m01 = { 0, 0 }, m10 = { 0, 0 }, m11 = { 1, 0 };
-        for (int g = md.begin; g < md.begin + md.count; ++g) {
-            const TileGate tg = a.gates[g];
-            const double2 cs = tab[tg.g];
-            const double c = cs.x, sn = cs.y;
-            const double r2 = 0.70710678118654752440;
-            c2 g00, g01, g10, g11;
-            switch (tg.kind) {
-            case VQA_GATE_H: g00 = { r2, 0 }; g01 = { r2, 0 }; g10 = { r2, 0 }; g11 = { -r2, 0 }; break;
-            case VQA_GATE_X: g00 = { 0, 0 }; g01 = { 1, 0 }; g10 = { 1, 0 }; g11 = { 0, 0 }; break;
-            case VQA_GATE_Y: g00 = { 0, 0 }; g01 = { 0, -1 }; g10 = { 0, 1 }; g11 = { 0, 0 }; break;
-            case VQA_GATE_Z: g00 = { 1, 0 }; g01 = { 0, 0 }; g10 = { 0, 0 }; g11 = { -1, 0 }; break;
-            case VQA_GATE_RX: g00 = { c, 0 }; g01 = { 0, sn }; g10 = { 0, sn }; g11 = { c, 0 }; break;
-            case VQA_GATE_RY: g00 = { c, 0 }; g01 = { sn, 0 }; g10 = { -sn, 0 }; g11 = { c, 0 }; break;
-            default: /* RZ */ g00 = { c, sn }; g01 = { 0, 0 }; g10 = { 0, 0 }; g11 = { c, -sn }; break;
-            }
-            const c2 n00 = ca(cm(g00, m00), cm(g01, m10)), n01 = ca(cm(g00, m01), cm(g01, m11));
-            const c2 n10 = ca(cm(g10, m00), cm(g11, m10)), n11 = ca(cm(g10, m01), cm(g11, m11));
-            m00 = n00; m01 = n01; m10 = n10; m11 = n11;
+    tab += (int64_t)ci * a.n_ops;
+    // local index l = k * kTT + tid (12 bits) -> global index; the low four bits are contiguous
+    // (state indices fit 32 bits: at most 30 qubits)
+    uint32_t g_tid = tid & ((1 << kTileLow) - 1);
+#pragma unroll
+    for (int j = kTileLow; j < kThreadBits; ++j) g_tid |= (uint32_t)((tid >> j) & 1) << a.tq[j];
+    uint32_t g_k[kTA];
+#pragma unroll
+    for (int k = 0; k < kTA; ++k) {
+        g_k[k] = 0;
+#pragma unroll
+        for (int j = kThreadBits; j < kTileBits; ++j) g_k[k] |= (uint32_t)((k >> (j - kThreadBits)) & 1) << a.tq[j];
+    }
+    const uint32_t w0 = blockIdx.x * (uint32_t)a.tiles_per_wg;
+    // the prefetched tile, as one vector value (an array carried around the tile loop would live in scratch)
+    typedef double pvec_t __attribute__((ext_vector_type(2 * kTA)));
+    pvec_t pv;
+    {
+        const uint32_t b0 = tile_base(a, w0);
+#pragma unroll
+        for (int k = 0; k < kTA; ++k) {
+            const double2 t2 = s[b0 | g_tid | g_k[k]];
+            pv[2 * k] = t2.x;
+            pv[2 * k + 1] = t2.y;
         }
-        smat[4 * k + 0] = make_double2(m00.x, m00.y);
-        smat[4 * k + 1] = make_double2(m01.x, m01.y);
-        smat[4 * k + 2] = make_double2(m10.x, m10.y);
-        smat[4 * k + 3] = make_double2(m11.x, m11.y);
     }
-    // gather: local index l (12 bits) -> global index; the low four bits are contiguous
-    int64_t g_tid = base | (tid & ((1 << kTileLow) - 1));
-    for (int j = kTileLow; j < 8; ++j) g_tid |= (int64_t)((tid >> j) & 1) << a.tq[j];
-    for (int k = 0; k < kTileAmps / kT; ++k) {
-        int64_t gidx = g_tid;
-        for (int j = 8; j < kTileBits; ++j) gidx |= (int64_t)((k >> (j - 8)) & 1) << a.tq[j];
-        tile[tile_slot(k * kT + tid)] = s[gidx];
+    // the pass's tables, into LDS while the first amplitudes are on their way
+    for (int k = tid; k < a.n_pops; k += kTT) s_ops[k] = ops[k];
+    for (int k = tid; k < a.n_sweeps * (int)(sizeof(SweepDesc) / 4); k += kTT)
+        reinterpret_cast<int32_t*>(s_sw)[k] = reinterpret_cast<const int32_t*>(sweeps)[k];
+    for (int k = tid; k < 4 * a.n_mats; k += kTT)
+        smat[k] = mats[((int64_t)ci * a.n_mats_total + a.mat_off) * 4 + k];
+    for (int k = tid; k < a.dg_total; k += kTT) {
+        const TileGate tg = gates[a.pg_begin + k];
+        s_dg[k] = tg;
+        if (k < a.pg_count) s_dcs[k] = tab[tg.g];
     }
-    for (int si = 0; si < a.n_sweeps; ++si) {
-        const SweepDesc& sw = a.sweeps[si];
-        const int dg_begin = sw.dg_begin, dg_count = (a.debug & 4) ? 0 : sw.dg_count, dg_cross = sw.dg_cross;
-        double2* dt = dtab[si & 1];
-        if (dg_count > 0 && tid < 128) {
-            // The phase of amplitude i factors into a part from its low six tile bits (and the
-            // outer bits, fixed here), a part from its high six, and the signs of the CZs that
-            // join the two halves (the first dg_cross gates of the run).
-            const int half = tid >> 6, i = half ? (tid & 63) << 6 : (tid & 63);
-            c2 ph = { 1.0, 0.0 };
-            bool neg = false;
-            for (int g = dg_begin + dg_cross; g < dg_begin + dg_count; ++g) {
-                const TileGate tg = a.gates[g];
-                const bool hi = (tg.p0 < 32 && tg.p0 >= 6) || (tg.p1 >= 6 && tg.p1 < 32);
-                if ((int)hi != half) continue;
-                if (tg.kind == VQA_GATE_RZ) {
-                    const double2 cs = tab[tg.g];
-                    ph = cm(ph, { cs.x, gate_bit(tg.p0, base, i) ? -cs.y : cs.y });
+    for (int t = 0; t < (kTilesPerWg > 1 ? a.tiles_per_wg : 1); ++t) {
+        const uint32_t base = tile_base(a, w0 + t);
+        lds_barrier();   // tables staged (t = 0) / the previous tile has left LDS
+        if (tid < a.n_sweeps) {
+            const SweepDesc& sd = s_sw[tid];
+            if (sd.dg_mode == DG_SIGN) {
+                // fold this tile's outer bits into the run's masks
+                SignRun sr;
+                sr.zmask = 0;
+                sr.neg0 = 0;
+#pragma unroll
+                for (int j = 0; j < kMaxShifts; ++j) sr.m[j] = 0;
+                for (int g = sd.dg_begin; g < sd.dg_begin + sd.dg_count; ++g) {
+                    const TileGate tg = s_dg[g];
+                    if (tg.kind == VQA_GATE_Z) {
+                        if (tg.p0 < 32) sr.zmask ^= 1 << tg.p0;
+                        else sr.neg0 ^= (int)((base >> (tg.p0 - 32)) & 1);
+                    } else if (tg.p0 < 32 && tg.p1 < 32) {
+                        const int lo = min(tg.p0, tg.p1), d = max(tg.p0, tg.p1) - lo;
+#pragma unroll
+                        for (int j = 0; j < kMaxShifts; ++j)
+                            if (j < sd.n_shift && sd.shift[j] == d) sr.m[j] ^= 1 << lo;
+                    } else if (tg.p0 < 32 || tg.p1 < 32) {
+                        const int pt = tg.p0 < 32 ? tg.p0 : tg.p1, po = tg.p0 < 32 ? tg.p1 : tg.p0;
+                        if ((base >> (po - 32)) & 1) sr.zmask ^= 1 << pt;
+                    } else {
+                        sr.neg0 ^= (int)((base >> (tg.p0 - 32)) & (base >> (tg.p1 - 32)) & 1);
+                    }
+                }
+                s_sign[tid] = sr;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kTA; ++k) tile[tile_slot(k * kTT + tid)] = make_double2(pv[2 * k], pv[2 * k + 1]);
+        if (kTilesPerWg > 1 && t + 1 < a.tiles_per_wg) {
+            const uint32_t b1 = tile_base(a, w0 + t + 1);
+#pragma unroll
+            for (int k = 0; k < kTA; ++k) {
+                const double2 t2 = s[b1 | g_tid | g_k[k]];
+                pv[2 * k] = t2.x;
+                pv[2 * k + 1] = t2.y;
+            }
+        }
+        for (int si = 0; si < a.n_sweeps; ++si) {
+            lds_barrier();   // the previous sweep's amplitudes (or the gathered tile) are in LDS
+            const SweepDesc& sw = s_sw[si];
+            const int dg_mode = uni(sw.dg_mode), dg_begin = uni(sw.dg_begin), dg_count = uni(sw.dg_count),
+                      dg_cross = uni(sw.dg_cross);
+            double2* dt = dtab[si & 1];
+            if (dg_mode == DG_PHASE) {
+                if (tid < 128) {
+                    // The phase of amplitude i factors into a part from its low six tile bits (and the
+                    // outer bits, fixed here), a part from its high six, and the gates that join the
+                    // two halves (the first dg_cross of the run).
+                    const int half = tid >> 6, i = half ? (tid & 63) << 6 : (tid & 63);
+                    c2 ph = { 1.0, 0.0 };
+                    bool neg = false;
+                    for (int g = dg_begin + dg_cross; g < dg_begin + dg_count; ++g) {
+                        const TileGate tg = s_dg[g];
+                        const bool hi = (tg.p0 < 32 && tg.p0 >= 6) || (tg.p1 >= 6 && tg.p1 < 32);
+                        if ((int)hi != half) continue;
+                        if (tg.kind == VQA_GATE_RZ) {
+                            const double2 cs = s_dcs[g];
+                            ph = cm(ph, { cs.x, gate_bit(tg.p0, base, i) ? -cs.y : cs.y });
+                        } else if (tg.kind == kGateZZ) {
+                            const double2 cs = s_dcs[g];
+                            ph = cm(ph, { cs.x, gate_bit(tg.p0, base, i) != gate_bit(tg.p1, base, i) ? -cs.y : cs.y });
+                        } else {
+                            bool f = gate_bit(tg.p0, base, i);
+                            if (tg.kind == VQA_GATE_CZ) f = f && gate_bit(tg.p1, base, i);
+                            neg ^= f;
+                        }
+                    }
+                    if (neg) ph = { -ph.x, -ph.y };
+                    dt[tid] = make_double2(ph.x, ph.y);
+                }
+                lds_barrier();
+            }
+            // this thread's amplitudes: thread bits on tpos, register bits on gpos
+            int ib = 0;
+#pragma unroll
+            for (int b = 0; b < kThreadBits; ++b) ib |= ((tid >> b) & 1) << uni(sw.tpos[b]);
+            int off[kTA];
+            {
+                int gp[4];
+#pragma unroll
+                for (int j = 0; j < kGroup; ++j) gp[j] = uni(sw.gpos[j]);
+#pragma unroll
+                for (int r = 0; r < kTA; ++r) {
+                    off[r] = 0;
+#pragma unroll
+                    for (int j = 0; j < kGroup; ++j) off[r] |= ((r >> j) & 1) << gp[j];
+                }
+            }
+            const int sb = tile_slot(ib);
+            double2 v[kTA];
+#pragma unroll
+            for (int r = 0; r < kTA; ++r) v[r] = tile[sb ^ tile_slot(off[r])];
+            const int o_end = uni(sw.op_begin) + uni(sw.op_count);
+            for (int o = uni(sw.op_begin); o < o_end; ++o) {
+                const GroupOp op = s_ops[o];
+                const int type = uni(op.type), slot = uni(op.slot), oa = uni(op.a);
+                if (type == OP_MAT) {
+                    const double2* m = &smat[4 * oa];
+                    switch (slot) {
+                    case 0: apply_mat<0>(v, m); break;
+                    case 1: apply_mat<1>(v, m); break;
+                    case 2: apply_mat<2>(v, m); break;
+                    default: if (kGroup > 3) apply_mat<kGroup - 1>(v, m); break;
+                    }
                 } else {
-                    bool f = gate_bit(tg.p0, base, i);
-                    if (tg.kind == VQA_GATE_CZ) f = f && gate_bit(tg.p1, base, i);
-                    neg ^= f;
+                    switch (slot) {
+                    case 0: apply_cnot<0>(v, oa, base, ib, off); break;
+                    case 1: apply_cnot<1>(v, oa, base, ib, off); break;
+                    case 2: apply_cnot<2>(v, oa, base, ib, off); break;
+                    default: if (kGroup > 3) apply_cnot<kGroup - 1>(v, oa, base, ib, off); break;
+                    }
                 }
             }
-            if (neg) ph = { -ph.x, -ph.y };
-            dt[tid] = make_double2(ph.x, ph.y);
-        }
-        __syncthreads();
-        // this thread's 16 amplitudes: thread bits on tpos, register bits on gpos
-        int ib = 0;
+            if (dg_mode == DG_PHASE) {
 #pragma unroll
-        for (int b = 0; b < kTileBits - kGroup; ++b) ib |= ((tid >> b) & 1) << sw.tpos[b];
-        int off[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            off[r] = ((r & 1) << sw.gpos[0]) | (((r >> 1) & 1) << sw.gpos[1]) | (((r >> 2) & 1) << sw.gpos[2]) |
-                     (((r >> 3) & 1) << sw.gpos[3]);
-        const int sb = tile_slot(ib);
-        double2 v[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = tile[sb ^ tile_slot(off[r])];
-        for (int o = sw.op_begin; o < sw.op_begin + ((a.debug & 2) ? 0 : sw.op_count); ++o) {
-            const GroupOp op = a.ops[o];
-            if (op.type == OP_MAT) {
-                const double2* m = &smat[4 * op.a];
-                switch (op.slot) {
-                case 0: apply_mat<0>(v, m); break;
-                case 1: apply_mat<1>(v, m); break;
-                case 2: apply_mat<2>(v, m); break;
-                default: apply_mat<3>(v, m); break;
+                for (int r = 0; r < kTA; ++r) {
+                    const int i = ib | off[r];
+                    const double2 lo = dt[i & 63], hi = dt[64 + (i >> 6)];
+                    c2 ph = cm({ lo.x, lo.y }, { hi.x, hi.y });
+                    for (int g = dg_begin; g < dg_begin + dg_cross; ++g) {
+                        const TileGate tg = s_dg[g];
+                        const int p0 = uni(tg.p0), p1 = uni(tg.p1);
+                        if (uni(tg.kind) == VQA_GATE_CZ) {
+                            if ((i >> p0) & (i >> p1) & 1) ph = { -ph.x, -ph.y };
+                        } else {
+                            const double2 cs = s_dcs[g];
+                            ph = cm(ph, { cs.x, (((i >> p0) ^ (i >> p1)) & 1) ? -cs.y : cs.y });
+                        }
+                    }
+                    const c2 rr = cm({ v[r].x, v[r].y }, ph);
+                    v[r] = make_double2(rr.x, rr.y);
+                    if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four amplitudes' table reads in flight, not all
                 }
-            } else {
-                switch (op.slot) {
-                case 0: apply_cnot<0>(v, op.a, base, ib, off); break;
-                case 1: apply_cnot<1>(v, op.a, base, ib, off); break;
-                case 2: apply_cnot<2>(v, op.a, base, ib, off); break;
-                default: apply_cnot<3>(v, op.a, base, ib, off); break;
+            } else if (dg_mode == DG_SIGN) {
+                const SignRun& sr = s_sign[si];
+                const int zmask = uni(sr.zmask), neg0 = uni(sr.neg0), n_shift = uni(sw.n_shift);
+                int sh[kMaxShifts], mk[kMaxShifts];
+#pragma unroll
+                for (int j = 0; j < kMaxShifts; ++j) {
+                    sh[j] = uni(sw.shift[j]);
+                    mk[j] = j < n_shift ? uni(sr.m[j]) : 0;
+                }
+#pragma unroll
+                for (int r = 0; r < kTA; ++r) {
+                    const int i = ib | off[r];
+                    int x = i & zmask;
+#pragma unroll
+                    for (int j = 0; j < kMaxShifts; ++j) x ^= i & (i >> sh[j]) & mk[j];
+                    if ((__popc(x) ^ neg0) & 1) v[r] = make_double2(-v[r].x, -v[r].y);
                 }
             }
-        }
-        if (dg_count > 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = ib | off[r];
-                const double2 lo = dt[i & 63], hi = dt[64 + (i >> 6)];
-                c2 ph = cm({ lo.x, lo.y }, { hi.x, hi.y });
-                bool neg = false;
-                for (int g = dg_begin; g < dg_begin + dg_cross; ++g) {
-                    const TileGate tg = a.gates[g];
-                    neg ^= ((i >> tg.p0) & (i >> tg.p1) & 1) != 0;
-                }
-                if (neg) ph = { -ph.x, -ph.y };
-                const c2 rr = cm({ v[r].x, v[r].y }, ph);
-                v[r] = make_double2(rr.x, rr.y);
-            }
+            for (int r = 0; r < kTA; ++r) tile[sb ^ tile_slot(off[r])] = v[r];
         }
+        lds_barrier();
 #pragma unroll
-        for (int r = 0; r < 16; ++r) tile[sb ^ tile_slot(off[r])] = v[r];
-    }
-    __syncthreads();
-    for (int k = 0; k < kTileAmps / kT; ++k) {
-        int64_t gidx = g_tid;
-        for (int j = 8; j < kTileBits; ++j) gidx |= (int64_t)((k >> (j - 8)) & 1) << a.tq[j];
-        s[gidx] = tile[tile_slot(k * kT + tid)];
+        for (int k = 0; k < kTA; ++k) s[base | g_tid | g_k[k]] = tile[tile_slot(k * kTT + tid)];
     }
 }
 
 // Cuts the gate list into passes.  A gate can run in a pass when its target (for
 // the non-diagonal kinds) is a tile qubit and none of its qubits is held back by
 // an earlier gate that could not run; gates that share no qubit commute, so
-// later gates on other qubits may run ahead of a held-back one.  Inside a pass
+// later gates on other qubits may run ahead of a held-back one.  A CNOT - RZ(target) -
+// CNOT sandwich is one diagonal ZZ phase gate.  Inside a pass
 // the gates are grouped into sweeps with the same argument: a gate goes into the
 // earliest sweep at or behind the last one that touches its qubits -- a 1-qubit gate or
 // CNOT into the sweep's register operations when its target is (or can become) one of the
-// sweep's four group positions and the sweep's diagonal run does not yet touch its qubits;
+// sweep's group positions and the sweep's diagonal run does not yet touch its qubits;
 // a diagonal gate into the diagonal run of the last sweep that touches its qubits.
 struct TilePlan {
     struct Pass {
         int tq[kTileBits];
-        std::vector<TileGate> gates;   // matrix gate lists and diagonal runs, in the order the descriptors name them
+        std::vector<TileGate> gates;   // register-operation gates, then the phase-list runs, then the signs-only runs
         std::vector<GroupOp> ops;
-        std::vector<MatDesc> mats;
+        std::vector<MatDesc> mats;     // gate ranges relative to this pass's gates
         std::vector<SweepDesc> sweeps;
+        int pg_begin = 0, pg_count = 0, dg_total = 0;
     };
     std::vector<Pass> passes;
     // images copied to the device: the passes' tables one after the other
     std::vector<TileGate> all_gates;
     std::vector<GroupOp> all_ops;
-    std::vector<MatDesc> all_mats;
+    std::vector<MatDesc> all_mats;     // gate ranges in all_gates
     std::vector<SweepDesc> all_sweeps;
     std::vector<size_t> goff, ooff, moff, soff;   // where each pass starts in the images
     std::vector<int> pass_of_gate;     // gate index -> the pass that runs it
@@ -406,11 +564,11 @@ static bool group_sweeps(TilePlan::Pass& pass, const std::vector<TileGate>& in_o
         return same < 2;
     };
     for (const TileGate& tg : in_order) {
-        const bool diag = tg.kind == VQA_GATE_RZ || tg.kind == VQA_GATE_Z || tg.kind == VQA_GATE_CZ;
+        const bool diag = tg.kind == VQA_GATE_RZ || tg.kind == VQA_GATE_Z || tg.kind == VQA_GATE_CZ || tg.kind == kGateZZ;
         std::pair<int, int> dep = last_of(tg.p0);
         if (tg.p1 >= 0) dep = std::max(dep, last_of(tg.p1));
         bool as_op = !diag;
-        if (diag && tg.kind != VQA_GATE_CZ && tg.p0 < 32 && dep.first >= 0 && dep.second == 0) {
+        if (diag && tg.p1 < 0 && tg.p0 < 32 && dep.first >= 0 && dep.second == 0) {
             // RZ / Z straight behind a fused 2x2 of its qubit joins that product
             const HSweep& sw = sweeps[dep.first];
             for (auto it = sw.ops.rbegin(); it != sw.ops.rend(); ++it) {
@@ -450,8 +608,10 @@ static bool group_sweeps(TilePlan::Pass& pass, const std::vector<TileGate>& in_o
         }
     }
     if ((int)sweeps.size() > kMaxSweeps) return false;
+    std::vector<TileGate> phase_list, sign_list;
     for (HSweep& hs : sweeps) {
         SweepDesc sd;
+        memset(&sd, 0, sizeof(sd));
         // fill the group with unused positions, then hand out the thread bits: bits 0..3 get one
         // position of each residue class mod 4 (classes 0, 1, 2 first), the rest ascending
         for (int p = kTileBits - 1; p >= 0 && (int)hs.gpos.size() < kGroup; --p)
@@ -467,7 +627,7 @@ static bool group_sweeps(TilePlan::Pass& pass, const std::vector<TileGate>& in_o
         }
         tp.insert(tp.end(), rest.begin(), rest.end());
         for (int j = 0; j < kGroup; ++j) sd.gpos[j] = hs.gpos[j];
-        for (int b = 0; b < kTileBits - kGroup; ++b) sd.tpos[b] = tp[b];
+        for (int b = 0; b < kThreadBits; ++b) sd.tpos[b] = tp[b];
         sd.op_begin = (int)pass.ops.size();
         for (const HOp& op : hs.ops) {
             const int slot = (int)(std::find(hs.gpos.begin(), hs.gpos.end(), op.pos) - hs.gpos.begin());
@@ -481,31 +641,72 @@ static bool group_sweeps(TilePlan::Pass& pass, const std::vector<TileGate>& in_o
             }
         }
         sd.op_count = (int)pass.ops.size() - sd.op_begin;
-        // CZs between the low six and the high six tile bits go first
-        auto cross = [](const TileGate& t) {
-            return t.kind == VQA_GATE_CZ && t.p0 < 32 && t.p1 < 32 && (t.p0 < 6) != (t.p1 < 6);
-        };
-        std::stable_partition(hs.diag.begin(), hs.diag.end(), cross);
-        sd.dg_begin = (int)pass.gates.size();
         sd.dg_count = (int)hs.diag.size();
-        sd.dg_cross = (int)std::count_if(hs.diag.begin(), hs.diag.end(), cross);
-        pass.gates.insert(pass.gates.end(), hs.diag.begin(), hs.diag.end());
+        if (!hs.diag.empty()) {
+            bool signs = true;
+            std::vector<int> shifts;
+            for (const TileGate& t : hs.diag) {
+                signs &= t.kind == VQA_GATE_Z || t.kind == VQA_GATE_CZ;
+                if (t.kind == VQA_GATE_CZ && t.p0 < 32 && t.p1 < 32) {
+                    const int d = std::abs(t.p0 - t.p1);
+                    if (std::find(shifts.begin(), shifts.end(), d) == shifts.end()) shifts.push_back(d);
+                }
+            }
+            if (signs && (int)shifts.size() <= kMaxShifts) {
+                sd.dg_mode = DG_SIGN;
+                sd.n_shift = (int)shifts.size();
+                for (size_t j = 0; j < shifts.size(); ++j) sd.shift[j] = shifts[j];
+                sd.dg_begin = (int)sign_list.size();            // moved behind the phase list below
+                sign_list.insert(sign_list.end(), hs.diag.begin(), hs.diag.end());
+            } else {
+                // gates between the low six and the high six tile bits go first
+                auto cross = [](const TileGate& t) {
+                    return (t.kind == VQA_GATE_CZ || t.kind == kGateZZ) && t.p0 < 32 && t.p1 < 32 && (t.p0 < 6) != (t.p1 < 6);
+                };
+                std::stable_partition(hs.diag.begin(), hs.diag.end(), cross);
+                sd.dg_mode = DG_PHASE;
+                sd.dg_cross = (int)std::count_if(hs.diag.begin(), hs.diag.end(), cross);
+                sd.dg_begin = (int)phase_list.size();           // index into the phase list
+                phase_list.insert(phase_list.end(), hs.diag.begin(), hs.diag.end());
+            }
+        }
         pass.sweeps.push_back(sd);
     }
-    return (int)pass.mats.size() <= kMaxMats && (int)pass.ops.size() <= kMaxOps;
+    pass.pg_begin = (int)pass.gates.size();
+    pass.pg_count = (int)phase_list.size();
+    pass.gates.insert(pass.gates.end(), phase_list.begin(), phase_list.end());
+    pass.gates.insert(pass.gates.end(), sign_list.begin(), sign_list.end());
+    pass.dg_total = pass.pg_count + (int)sign_list.size();
+    for (SweepDesc& sd : pass.sweeps)
+        if (sd.dg_mode == DG_SIGN) sd.dg_begin += pass.pg_count;   // both kinds index the pass's diagonal list
+    return (int)pass.mats.size() <= kMaxMats && (int)pass.ops.size() <= kMaxOps && pass.pg_count <= kMaxPhaseGates &&
+           pass.dg_total <= kMaxDiagGates;
 }
 
 static TilePlan plan_tiles(int n, const std::vector<vqa_op>& ops) {
     TilePlan plan;
-    std::vector<int> todo(ops.size());
-    for (size_t i = 0; i < ops.size(); ++i) todo[i] = (int)i;
-    auto diagonal = [](int kind) { return kind == VQA_GATE_RZ || kind == VQA_GATE_Z || kind == VQA_GATE_CZ; };
+    // the gate list with CNOT(c,t) RZ_t CNOT(c,t) sandwiches as ZZ phase gates
+    struct PG { int kind, q0, q1, g; };
+    std::vector<PG> pg;
+    for (size_t i = 0; i < ops.size(); ++i) {
+        const vqa_op& op = ops[i];
+        if (op.kind == VQA_GATE_CNOT && i + 2 < ops.size() && ops[i + 1].kind == VQA_GATE_RZ && ops[i + 1].q0 == op.q0 &&
+            ops[i + 2].kind == VQA_GATE_CNOT && ops[i + 2].q0 == op.q0 && ops[i + 2].q1 == op.q1) {
+            pg.push_back(PG{ kGateZZ, op.q0, op.q1, (int)i + 1 });
+            i += 2;
+        } else {
+            pg.push_back(PG{ op.kind, op.q0, op.q1, (int)i });
+        }
+    }
+    std::vector<int> todo(pg.size());
+    for (size_t i = 0; i < pg.size(); ++i) todo[i] = (int)i;
+    auto diagonal = [](int kind) { return kind == VQA_GATE_RZ || kind == VQA_GATE_Z || kind == VQA_GATE_CZ || kind == kGateZZ; };
     while (!todo.empty()) {
         // tile: the low qubits plus the first eight others that pending gates need as targets
         std::vector<int> tile;
         for (int q = 0; q < kTileLow; ++q) tile.push_back(q);
         for (int gi : todo) {
-            const vqa_op& op = ops[gi];
+            const PG& op = pg[gi];
             if (diagonal(op.kind) || op.q0 < kTileLow) continue;
             if (std::find(tile.begin(), tile.end(), op.q0) == tile.end()) tile.push_back(op.q0);
             if ((int)tile.size() == kTileBits) break;
@@ -523,7 +724,7 @@ static TilePlan plan_tiles(int n, const std::vector<vqa_op>& ops) {
             std::vector<int> rest;
             std::vector<TileGate> taken;
             for (int gi : todo) {
-                const vqa_op& op = ops[gi];
+                const PG& op = pg[gi];
                 const uint64_t qs = ((uint64_t)1 << op.q0) | (op.q1 >= 0 ? (uint64_t)1 << op.q1 : 0);
                 const bool ok = !(held & qs) && (diagonal(op.kind) || pos_of[op.q0] < 32) &&
                                 (int)taken.size() < cap;
@@ -532,7 +733,7 @@ static TilePlan plan_tiles(int n, const std::vector<vqa_op>& ops) {
                     rest.push_back(gi);
                     continue;
                 }
-                taken.push_back(TileGate{ op.kind, pos_of[op.q0], op.q1 >= 0 ? pos_of[op.q1] : -1, gi });
+                taken.push_back(TileGate{ op.kind, pos_of[op.q0], op.q1 >= 0 ? pos_of[op.q1] : -1, op.g });
             }
             if (!group_sweeps(pass, taken) && cap > 1) continue;
             todo.swap(rest);
@@ -547,9 +748,9 @@ static TilePlan plan_tiles(int n, const std::vector<vqa_op>& ops) {
         plan.ooff.push_back(plan.all_ops.size());
         plan.moff.push_back(plan.all_mats.size());
         plan.soff.push_back(plan.all_sweeps.size());
+        for (const MatDesc& md : p.mats) plan.all_mats.push_back(MatDesc{ md.begin + (int)plan.all_gates.size(), md.count });
         plan.all_gates.insert(plan.all_gates.end(), p.gates.begin(), p.gates.end());
         plan.all_ops.insert(plan.all_ops.end(), p.ops.begin(), p.ops.end());
-        plan.all_mats.insert(plan.all_mats.end(), p.mats.begin(), p.mats.end());
         plan.all_sweeps.insert(plan.all_sweeps.end(), p.sweeps.begin(), p.sweeps.end());
         for (const TileGate& tg : p.gates) plan.pass_of_gate[tg.g] = (int)k;
     }
@@ -893,6 +1094,12 @@ size_t gate_buf_bytes(const EvalCall& call) {
            pad256(g * sizeof(SweepDesc));
 }
 
+// bytes of the fused-2x2 table of C instances
+size_t mats_bytes(const EvalCall& call, int64_t C) {
+    const size_t M = tiled(call) ? std::max<size_t>(plan_of(call).all_mats.size(), 1) : 1;
+    return pad256((size_t)C * M * 4 * sizeof(double2));
+}
+
 PlanImage plan_image(const EvalCall& call, void* gate_buf) {
     const size_t g = (size_t)std::max(call.c->n_ops, 1);
     char* w = (char*)gate_buf;
@@ -925,15 +1132,25 @@ int upload_plan(const EvalCall& call, const TilePlan& plan, void* gate_buf) {
     return VQA_OK;
 }
 
-// pass k of the plan on C states side by side (st, their angle tables at tab)
+// the fused 2x2s of C instances from their angle tables
+void launch_mats(const EvalCall& call, const TilePlan& plan, void* gate_buf, const double2* tab, double2* mats, int C) {
+    const int M = (int)plan.all_mats.size();
+    if (M == 0 || C <= 0) return;
+    const PlanImage im = plan_image(call, gate_buf);
+    const int64_t tot = (int64_t)C * M;
+    hipLaunchKernelGGL(k_mats, dim3((unsigned)((tot + kT - 1) / kT)), dim3(kT), 0, call.stream, im.gates, im.mats, M, tab,
+                       call.c->n_ops, C, mats);
+}
+
+// pass k of the plan on C states side by side (st; their angle tables at tab, their fused 2x2s at mats)
 void launch_pass(const EvalCall& call, const TilePlan& plan, size_t k, void* gate_buf, double2* st,
-                 const double2* tab, int C) {
+                 const double2* tab, const double2* mats, int C) {
     const auto& p = plan.passes[k];
     if (p.gates.empty() || C <= 0) return;
     const int n = call.c->n_qubits;
     const PlanImage im = plan_image(call, gate_buf);
     TilePassArgs a;
-    a.n = n; a.C = C; a.n_ops = call.c->n_ops;
+    a.n = n; a.n_ops = call.c->n_ops;
     a.n_outer = 0;
     for (int q = 0; q < n; ++q) {
         bool in_tile = false;
@@ -941,22 +1158,26 @@ void launch_pass(const EvalCall& call, const TilePlan& plan, size_t k, void* gat
         if (!in_tile) a.oq[a.n_outer++] = q;
     }
     for (int t = 0; t < kTileBits; ++t) a.tq[t] = p.tq[t];
-    a.gates = im.gates + plan.goff[k];
-    a.ops = im.ops + plan.ooff[k];
-    a.mats = im.mats + plan.moff[k];
-    a.sweeps = im.sweeps + plan.soff[k];
     a.n_mats = (int)p.mats.size();
+    a.n_pops = (int)p.ops.size();
     a.n_sweeps = (int)p.sweeps.size();
-    a.tab = tab;
-    static const int dbg = getenv("VQA_TILE_DEBUG") ? atoi(getenv("VQA_TILE_DEBUG")) : 0;
-    a.debug = dbg;
-    if (dbg & 1) a.n_sweeps = 0;              // gather and scatter only
+    a.pg_begin = p.pg_begin;
+    a.pg_count = p.pg_count;
+    a.dg_total = p.dg_total;
+    a.mat_off = (int)plan.moff[k];
+    a.n_mats_total = (int)plan.all_mats.size();
     const int64_t D = (int64_t)1 << n;
-    hipLaunchKernelGGL(k_tile_pass, dim3((unsigned)(D >> kTileBits), C), dim3(kT),
-                       kTileAmps * sizeof(double2), call.stream, st, a);
+    // enough workgroups to fill the GPU a few times over, else several tiles per workgroup
+    const int64_t n_tiles = D >> kTileBits;
+    int tpw = 1;
+    while (tpw < kTilesPerWg && n_tiles % (2 * tpw) == 0 && (n_tiles / (2 * tpw)) * C >= 2048) tpw *= 2;
+    a.tiles_per_wg = tpw;
+    hipLaunchKernelGGL(k_tile_pass, dim3((unsigned)(n_tiles / tpw), C), dim3(kTT), kTileAmps * sizeof(double2),
+                       call.stream, st, im.gates + plan.goff[k], im.ops + plan.ooff[k], im.sweeps + plan.soff[k], tab,
+                       mats, a);
 }
 
-int launch_gates(const EvalCall& call, const HbmCommon& h, double2* st, double2* tab, void* gate_buf) {
+int launch_gates(const EvalCall& call, const HbmCommon& h, double2* st, double2* tab, void* gate_buf, double2* mats) {
     const int n = h.n, C = h.C;
     const int64_t D = (int64_t)1 << n;
     const int64_t tot = D * C;
@@ -970,7 +1191,8 @@ int launch_gates(const EvalCall& call, const HbmCommon& h, double2* st, double2*
         const TilePlan& plan = plan_of(call);
         int rc = upload_plan(call, plan, gate_buf);
         if (rc) return rc;
-        for (size_t k = 0; k < plan.passes.size(); ++k) launch_pass(call, plan, k, gate_buf, st, tab, C);
+        launch_mats(call, plan, gate_buf, tab, mats, C);
+        for (size_t k = 0; k < plan.passes.size(); ++k) launch_pass(call, plan, k, gate_buf, st, tab, mats, C);
         VQA_HIP(hipGetLastError());
         return VQA_OK;
     }
@@ -1113,13 +1335,15 @@ int hbm_engine_run(const EvalCall& call) {
     const size_t tab_bytes = ((size_t)Cmax * std::max(call.c->n_ops, 1) * sizeof(double2) + 255) & ~(size_t)255;
     const size_t part_bytes = ((size_t)Cmax * nb * kZBatch * sizeof(double) + 255) & ~(size_t)255;
     const size_t gate_bytes = gate_buf_bytes(call);
+    const size_t mat_bytes = mats_bytes(call, Cmax);
     void* ws = nullptr;
-    rc = workspace_get(call.device, st_bytes + tab_bytes + part_bytes + gate_bytes, &ws);
+    rc = workspace_get(call.device, st_bytes + tab_bytes + part_bytes + gate_bytes + mat_bytes, &ws);
     if (rc) return rc;
     double2* st = (double2*)ws;
     double2* tab = (double2*)((char*)ws + st_bytes);
     double* partial = (double*)((char*)ws + st_bytes + tab_bytes);
     void* gate_buf = (char*)ws + st_bytes + tab_bytes + part_bytes;
+    double2* mats = (double2*)((char*)gate_buf + gate_bytes);
 
     for (int64_t e0 = 0; e0 < call.E; e0 += Cmax) {
         HbmCommon h;
@@ -1132,7 +1356,7 @@ int hbm_engine_run(const EvalCall& call) {
         h.spec = call.spec;
         h.e_base = e0;
         h.C = (int)std::min<int64_t>(Cmax, call.E - e0);
-        rc = launch_gates(call, h, st, tab, gate_buf);
+        rc = launch_gates(call, h, st, tab, gate_buf, mats);
         if (rc) return rc;
         rc = measure_states(call, st, h.C, e0, nb, partial, nullptr);
         if (rc) return rc;
@@ -1171,8 +1395,10 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
     const size_t ord_bytes = pad((size_t)std::max(m, 1) * sizeof(int32_t));
     const size_t coef_bytes = pad((size_t)std::max(m, 1) * sizeof(double));
     const size_t unused_bytes = pad((size_t)std::max(n_unused, 1) * sizeof(int32_t));
+    const size_t mat_bytes = mats_bytes(call, C + 2);
+    const size_t M4 = std::max<size_t>(plan.all_mats.size(), 1) * 4;   // double2 per instance in the matrix table
     void* ws = nullptr;
-    rc = workspace_get(call.device, st_bytes + tab_bytes + part_bytes + gate_bytes + ord_bytes + coef_bytes + unused_bytes, &ws);
+    rc = workspace_get(call.device, st_bytes + tab_bytes + part_bytes + gate_bytes + ord_bytes + coef_bytes + unused_bytes + mat_bytes, &ws);
     if (rc) return rc;
     char* w = (char*)ws;
     double2* st = (double2*)w;                 w += st_bytes;
@@ -1181,7 +1407,8 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
     void* gate_buf = w;                        w += gate_bytes;
     int32_t* d_ord = (int32_t*)w;              w += ord_bytes;
     double* d_coef = (double*)w;               w += coef_bytes;
-    int32_t* d_unused = (int32_t*)w;
+    int32_t* d_unused = (int32_t*)w;           w += unused_bytes;
+    double2* mats = (double2*)w;
     rc = upload_plan(call, plan, gate_buf);
     if (rc) return rc;
     if (m > 0) {
@@ -1211,7 +1438,8 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
         hipLaunchKernelGGL(k_init, dim3(gD), dim3(kT), 0, call.stream, F, D, D);
         if (h.n_ops > 0)
             hipLaunchKernelGGL(k_angles, dim3((unsigned)((h.n_ops + kT - 1) / kT)), dim3(kT), 0, call.stream, h, tab);
-        for (size_t k = 0; k < n_pass; ++k) launch_pass(call, plan, k, gate_buf, F, tab, 1);
+        launch_mats(call, plan, gate_buf, tab, mats, 1);
+        for (size_t k = 0; k < n_pass; ++k) launch_pass(call, plan, k, gate_buf, F, tab, mats, 1);
         rc = measure_states(call, F, 1, row0, nb, partial, nullptr);
         if (rc) return rc;
         if (n_unused > 0) {
@@ -1234,7 +1462,8 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
             const int64_t na = (int64_t)(cnt + 2) * h.n_ops;
             hipLaunchKernelGGL(k_sweep_angles, dim3((unsigned)((na + kT - 1) / kT)), dim3(kT), 0, call.stream, h, j,
                                d_ord + a, cnt + 2, tab);
-            for (; rpass < k0; ++rpass) launch_pass(call, plan, rpass, gate_buf, R, tab + n_ops, 1);
+            launch_mats(call, plan, gate_buf, tab, mats, cnt + 2);
+            for (; rpass < k0; ++rpass) launch_pass(call, plan, rpass, gate_buf, R, tab + n_ops, mats + M4, 1);
             int live = 0;
             for (size_t k = k0; k < n_pass; ++k) {
                 int fresh = 0;
@@ -1244,10 +1473,10 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
                 live += fresh;
                 if (k < k1) {
                     // the running state moves on with the chunk while later passes still take copies of it
-                    launch_pass(call, plan, k, gate_buf, R, tab + n_ops, live + 1);
+                    launch_pass(call, plan, k, gate_buf, R, tab + n_ops, mats + M4, live + 1);
                     rpass = k + 1;
                 } else {
-                    launch_pass(call, plan, k, gate_buf, S, tab + 2 * (size_t)n_ops, live);
+                    launch_pass(call, plan, k, gate_buf, S, tab + 2 * (size_t)n_ops, mats + 2 * M4, live);
                 }
             }
             PairArgs pa = { F, row0, d_ord + a, d_coef + a, call.spec.shift };
@@ -1265,7 +1494,7 @@ int hbm_engine_statevector(const EvalCall& call, double* d_out_state) {
     const size_t tab_bytes = ((size_t)std::max(call.c->n_ops, 1) * sizeof(double2) + 255) & ~(size_t)255;
     const size_t gate_bytes = gate_buf_bytes(call);
     void* ws = nullptr;
-    int rc = workspace_get(call.device, tab_bytes + gate_bytes, &ws);
+    int rc = workspace_get(call.device, tab_bytes + gate_bytes + mats_bytes(call, 1), &ws);
     if (rc) return rc;
     HbmCommon h;
     h.n = n;
@@ -1277,7 +1506,8 @@ int hbm_engine_statevector(const EvalCall& call, double* d_out_state) {
     h.spec = call.spec;
     h.e_base = 0;
     h.C = 1;
-    return launch_gates(call, h, (double2*)d_out_state, (double2*)ws, (char*)ws + tab_bytes);
+    return launch_gates(call, h, (double2*)d_out_state, (double2*)ws, (char*)ws + tab_bytes,
+                        (double2*)((char*)ws + tab_bytes + gate_bytes));
 }
 
 }  // namespace vqa
