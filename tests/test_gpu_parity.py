@@ -284,6 +284,36 @@ def test_pauli_sum_ring_hamiltonian():
     assert np.abs(got - want).max() < 1e-9   # 32 terms of order one: absolute 1e-10 per term
 
 
+@pytest.mark.parametrize("n,d", [(14, 2), (15, 1)])
+def test_streaming_sweep_with_pauli_sums(n, d):
+    """Full sweeps on the HBM engine with several observables at once: Z-strings of different
+    observables batched together, pure-X terms measured behind a Hadamard layer, mixed X/Y/Z
+    strings one by one; every instance against the oracle."""
+    c = create_ry_cz_ansatz(n, d, seed=4)
+    rng = np.random.default_rng(n)
+    theta = rng.uniform(-np.pi, np.pi, c.n_theta)
+    tfim = Observable(n)
+    for i in range(n):
+        tfim.add_operator(1.0, f"Z {i} Z {(i + 1) % n}")
+        tfim.add_operator(0.7, f"X {i}")
+    mixed = Observable(n)
+    mixed.add_operator(0.5, "X 0 X 5")
+    mixed.add_operator(-0.3, f"Y 2 Z {n - 1}")
+    mixed.add_operator(0.2, f"X 1 Z 3 Y {n - 2}")
+    mixed.add_operator(0.1, "")
+    z0 = Observable(n); z0.add_operator(1.0, "Z 0")
+    obs = [tfim, mixed, z0]
+    ia = c.input_angles(np.zeros((1, 1)))
+    si, sp, sv = cpu_oracle.psr_lists(1, c.n_theta)
+    want_e, want_m = cpu_oracle.eval_batch(c, theta, ia, si, sp, sv, obs_list=obs_tuples(obs), n_marg_bits=2)
+    got_e, got_m = c.psr_full(theta, ia, obs_list=obs, n_marg_bits=2)
+    assert np.abs(got_e.reshape(want_e.shape) - want_e).max() < 1e-9   # sums of up to 2n terms of order one
+    assert np.abs(got_m.reshape(want_m.shape) - want_m).max() < TOL
+    # the explicit instance list takes the same measurement path without the pairs
+    got_e2, _ = c.eval_batch(theta, ia, si[:7], sp[:7], sv[:7], obs_list=obs)
+    assert np.abs(got_e2 - want_e[:7]).max() < 1e-9
+
+
 def test_tiled_passes_against_gate_sweeps_22_qubits():
     """Beyond what the oracle finishes quickly: the tiled passes of the HBM engine against its
     one-sweep-per-gate form (independent kernels) on a 22-qubit circuit with all gate kinds."""

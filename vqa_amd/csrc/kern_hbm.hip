@@ -228,7 +228,8 @@ __global__ __launch_bounds__(kT) void k_mats(const TileGate* __restrict__ gates,
     c2 m00 = { 1, 0 }, m01 = { 0, 0 }, m10 = { 0, 0 }, m11 = { 1, 0 };
     for (int g = md.begin; g < md.begin + md.count; ++g) {
         const TileGate tg = gates[g];
-        const double2 cs = tab[(int64_t)ci * n_ops + tg.g];
+        const bool rot = tg.kind >= VQA_GATE_RX && tg.kind <= VQA_GATE_RZ;   // the others have no table entry to read
+        const double2 cs = rot ? tab[(int64_t)ci * n_ops + tg.g] : make_double2(1.0, 0.0);
         const double c = cs.x, sn = cs.y;
         const double r2 = 0.70710678118654752440;
         c2 g00, g01, g10, g11;
@@ -790,6 +791,7 @@ struct ZBatch {
     int nz;
     uint64_t z[kZBatch];
     double coef[kZBatch];
+    int col[kZBatch];  // output column (observable) each term adds to
     int marg_bits;  // > 0: bins m0 .. m0+nz-1 of the low-bit marginal instead of Z-strings
     int m0;
 };
@@ -857,13 +859,26 @@ __global__ __launch_bounds__(kT) void k_xpart(const double2* st, int n, uint64_t
 }
 
 // stage 2: out[(e_base + ci) * stride + col0 + t] (+)= coef_t * sum_blk partial
+// expectation outputs of C instances start at 0 (NaN for an instance that names a sample or
+// parameter that does not exist); the finishing kernels add their terms
+__global__ __launch_bounds__(kT) void k_out_init(double* out, int64_t e_base, int C, int stride, EvalSpec spec) {
+    const int i = blockIdx.x * kT + threadIdx.x;
+    if (i >= C * stride) return;
+    const int ci = i / stride;
+    int b_, sp_;
+    double sv_;
+    const bool valid = decode_eval(spec, e_base + ci, b_, sp_, sv_);
+    out[(e_base + ci) * stride + (i - ci * stride)] = valid ? 0.0 : __longlong_as_double(0x7ff8000000000000LL);
+}
+
+// stage 2: marginal bins (spread): out[(e_base + ci) * stride + col0 + t] = sum_blk partial;
+// expectation terms: out[(e_base + ci) * stride + column of t] += coef_t * sum_blk partial
 __global__ __launch_bounds__(kT) void k_finish(const double* partial, int nb, int nz, ZBatch zb,
                                                int use_coef, double xcoef, double* out,
                                                int64_t e_base, int stride, int col0, int spread,
-                                               int accumulate, EvalSpec spec) {
+                                               EvalSpec spec) {
     __shared__ double red[4];
     const int ci = blockIdx.x;
-    double total = 0.0;
     bool valid;
     {
         int b_, sp_;
@@ -878,14 +893,10 @@ __global__ __launch_bounds__(kT) void k_finish(const double* partial, int nb, in
         if (threadIdx.x == 0) {
             if (spread) {  // one output column per t (marginal bins)
                 out[(e_base + ci) * stride + col0 + t] = valid ? r : nanv;
-            } else {
-                total += (use_coef ? zb.coef[t] : xcoef) * r;
+            } else {       // NaN from k_out_init stays NaN
+                out[(e_base + ci) * stride + (use_coef ? zb.col[t] : col0)] += (use_coef ? zb.coef[t] : xcoef) * r;
             }
         }
-    }
-    if (!spread && threadIdx.x == 0) {
-        double* o = &out[(e_base + ci) * stride + col0];
-        *o = !valid ? nanv : accumulate ? *o + total : total;
     }
 }
 
@@ -1002,19 +1013,31 @@ __global__ __launch_bounds__(kT) void k_xpart2(const double2* f, const double2* 
     }
 }
 
-// stage 2 for state pairs: rows 2i+1 (+) and 2i+2 (-) of sample j, i = ord[ci]
-//   first flush of a column:   c^2 * (row 0 of the sample) + s^2 A +- 2 c s X
-//   later flushes:             += s^2 A +- 2 c s X
+// expectation rows 2i+1 (+) and 2i+2 (-) of a sample start at c^2 * (row 0 of the sample), i = ord[ci]
+__global__ __launch_bounds__(kT) void k_out_init2(double* out, int64_t row0, const int32_t* ord, const double* ord_coef,
+                                                  double shift, int C, int stride) {
+    const int i = blockIdx.x * kT + threadIdx.x;
+    if (i >= C * stride) return;
+    const int ci = i / stride, col = i - ci * stride;
+    const double c = cos(0.5 * ord_coef[ci] * shift);
+    const int64_t rp = row0 + 2 * (int64_t)ord[ci] + 1;
+    const double base = c * c * out[row0 * stride + col];
+    out[rp * stride + col] = base;
+    out[(rp + 1) * stride + col] = base;
+}
+
+// stage 2 for state pairs: rows 2i+1 (+) and 2i+2 (-) of sample j, i = ord[ci]:
+//   marginal bins (spread):  c^2 * (row 0 of the sample) + s^2 A +- 2 c s X
+//   expectation terms:       += coef (s^2 A +- 2 c s X) in the term's column
 __global__ __launch_bounds__(kT) void k_finish2(const double* partial, int nb, int nz, ZBatch zb, int use_coef,
                                                 double xcoef, double* out, int64_t row0, const int32_t* ord,
                                                 const double* ord_coef, double shift, int stride, int col0,
-                                                int spread, int accumulate) {
+                                                int spread) {
     __shared__ double red[4];
     const int ci = blockIdx.x;
     double sn, c;
     sincos(0.5 * ord_coef[ci] * shift, &sn, &c);
     const int64_t rp = row0 + 2 * (int64_t)ord[ci] + 1, rm = rp + 1;
-    double ta = 0.0, tx = 0.0;
     for (int t = 0; t < nz; ++t) {
         double va = 0.0, vx = 0.0;
         for (int b = threadIdx.x; b < nb; b += kT) {
@@ -1031,17 +1054,11 @@ __global__ __launch_bounds__(kT) void k_finish2(const double* partial, int nb, i
                 out[rm * stride + col0 + t] = base + sn * sn * a - 2.0 * c * sn * x;
             } else {
                 const double cf = use_coef ? zb.coef[t] : xcoef;
-                ta += cf * a;
-                tx += cf * x;
+                const int col = use_coef ? zb.col[t] : col0;
+                out[rp * stride + col] += cf * (sn * sn * a + 2.0 * c * sn * x);
+                out[rm * stride + col] += cf * (sn * sn * a - 2.0 * c * sn * x);
             }
         }
-    }
-    if (!spread && threadIdx.x == 0) {
-        double* op = &out[rp * stride + col0];
-        double* om = &out[rm * stride + col0];
-        const double base = c * c * out[row0 * stride + col0];
-        *op = (accumulate ? *op : base) + sn * sn * ta + 2.0 * c * sn * tx;
-        *om = (accumulate ? *om : base) + sn * sn * ta - 2.0 * c * sn * tx;
     }
 }
 
@@ -1077,9 +1094,35 @@ const TilePlan& plan_of(const EvalCall& call) {
     return *static_cast<const TilePlan*>(call.c->hbm_plan.get());
 }
 
+// The plan of a layer of Hadamards on the qubits of `mask`: it turns X factors of Pauli
+// strings into Z factors, so that many X-type terms are measured in one pass over the state.
+constexpr int kHGates = 32;
+const TilePlan& hplan_of(const EvalCall& call, uint64_t mask) {
+    std::lock_guard<std::mutex> lk(call.c->mu);
+    auto it = call.c->hbm_hplans.find(mask);
+    if (it == call.c->hbm_hplans.end()) {
+        std::vector<vqa_op> ops;
+        for (int q = 0; q < call.c->n_qubits; ++q)
+            if ((mask >> q) & 1) ops.push_back(vqa_op{ VQA_GATE_H, q, -1, VQA_SRC_CONST, 0, 0, 0.0, 0.0 });
+        it = call.c->hbm_hplans.emplace(mask, std::make_shared<TilePlan>(plan_tiles(call.c->n_qubits, ops))).first;
+    }
+    return *static_cast<const TilePlan*>(it->second.get());
+}
+
 bool tiled(const EvalCall& call) { return call.c->n_qubits >= kTileBits + 1 && call.c->engine != 4; }
 
-// device images of the plan: gates | ops | mats | sweeps, each sized for the whole circuit
+// The qubits of the Hadamard layer for this call's observables: the union of the X masks of
+// the pure-X terms, when there are enough of them to pay for the extra passes.
+uint64_t hlayer_mask(const EvalCall& call) {
+    if (!tiled(call)) return 0;
+    uint64_t mask = 0;
+    int count = 0;
+    for (int t = 0; t < call.obs.n_terms; ++t)
+        if (call.obs.x[t] != 0 && call.obs.z[t] == 0) { mask |= call.obs.x[t]; ++count; }
+    return count >= 3 ? mask : 0;
+}
+
+// device images of a plan: gates | ops | mats | sweeps, each sized for g gates
 struct PlanImage {
     TileGate* gates;
     GroupOp* ops;
@@ -1088,20 +1131,14 @@ struct PlanImage {
 };
 static size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
 
-size_t gate_buf_bytes(const EvalCall& call) {
-    const size_t g = (size_t)std::max(call.c->n_ops, 1);
+size_t gate_buf_bytes(size_t g) {
+    g = std::max<size_t>(g, 1);
     return pad256(g * sizeof(TileGate)) + pad256(g * sizeof(GroupOp)) + pad256(g * sizeof(MatDesc)) +
            pad256(g * sizeof(SweepDesc));
 }
 
-// bytes of the fused-2x2 table of C instances
-size_t mats_bytes(const EvalCall& call, int64_t C) {
-    const size_t M = tiled(call) ? std::max<size_t>(plan_of(call).all_mats.size(), 1) : 1;
-    return pad256((size_t)C * M * 4 * sizeof(double2));
-}
-
-PlanImage plan_image(const EvalCall& call, void* gate_buf) {
-    const size_t g = (size_t)std::max(call.c->n_ops, 1);
+PlanImage plan_image(size_t g, void* gate_buf) {
+    g = std::max<size_t>(g, 1);
     char* w = (char*)gate_buf;
     PlanImage im;
     im.gates = (TileGate*)w;   w += pad256(g * sizeof(TileGate));
@@ -1111,10 +1148,21 @@ PlanImage plan_image(const EvalCall& call, void* gate_buf) {
     return im;
 }
 
-// copies the plan's tables (the plan lives as long as the circuit, so the asynchronous
+// A plan with its device images and the fused-2x2 table of the instances it runs on.
+struct PlanDev {
+    const TilePlan* plan = nullptr;
+    size_t g = 0;            // gates the images are sized for
+    void* buf = nullptr;     // gate_buf_bytes(g)
+    double2* mats = nullptr; // [instances][all_mats][4]
+    size_t m4() const { return std::max<size_t>(plan->all_mats.size(), 1) * 4; }   // double2 per instance
+    size_t mats_bytes(int64_t C) const { return pad256((size_t)C * m4() * sizeof(double2)); }
+};
+
+// copies the plan's tables (a plan lives as long as its circuit, so the asynchronous
 // copies may read its host images after this returns)
-int upload_plan(const EvalCall& call, const TilePlan& plan, void* gate_buf) {
-    const PlanImage im = plan_image(call, gate_buf);
+int upload_plan(const EvalCall& call, const PlanDev& pd) {
+    const TilePlan& plan = *pd.plan;
+    const PlanImage im = plan_image(pd.g, pd.buf);
     if (!plan.all_gates.empty())
         VQA_HIP(hipMemcpyAsync(im.gates, plan.all_gates.data(), plan.all_gates.size() * sizeof(TileGate),
                                hipMemcpyHostToDevice, call.stream));
@@ -1132,25 +1180,26 @@ int upload_plan(const EvalCall& call, const TilePlan& plan, void* gate_buf) {
     return VQA_OK;
 }
 
-// the fused 2x2s of C instances from their angle tables
-void launch_mats(const EvalCall& call, const TilePlan& plan, void* gate_buf, const double2* tab, double2* mats, int C) {
-    const int M = (int)plan.all_mats.size();
+// the fused 2x2s of C instances (table rows slot0 ..) from their angle tables (tab_stride entries each)
+void launch_mats(const EvalCall& call, const PlanDev& pd, const double2* tab, int tab_stride, int slot0, int C) {
+    const int M = (int)pd.plan->all_mats.size();
     if (M == 0 || C <= 0) return;
-    const PlanImage im = plan_image(call, gate_buf);
+    const PlanImage im = plan_image(pd.g, pd.buf);
     const int64_t tot = (int64_t)C * M;
     hipLaunchKernelGGL(k_mats, dim3((unsigned)((tot + kT - 1) / kT)), dim3(kT), 0, call.stream, im.gates, im.mats, M, tab,
-                       call.c->n_ops, C, mats);
+                       tab_stride, C, pd.mats + (size_t)slot0 * pd.m4());
 }
 
-// pass k of the plan on C states side by side (st; their angle tables at tab, their fused 2x2s at mats)
-void launch_pass(const EvalCall& call, const TilePlan& plan, size_t k, void* gate_buf, double2* st,
-                 const double2* tab, const double2* mats, int C) {
+// pass k of the plan on C states side by side (st; their angle tables at tab, table rows slot0 .. of the fused 2x2s)
+void launch_pass(const EvalCall& call, const PlanDev& pd, size_t k, double2* st, const double2* tab, int tab_stride,
+                 int slot0, int C) {
+    const TilePlan& plan = *pd.plan;
     const auto& p = plan.passes[k];
     if (p.gates.empty() || C <= 0) return;
     const int n = call.c->n_qubits;
-    const PlanImage im = plan_image(call, gate_buf);
+    const PlanImage im = plan_image(pd.g, pd.buf);
     TilePassArgs a;
-    a.n = n; a.n_ops = call.c->n_ops;
+    a.n = n; a.n_ops = tab_stride;
     a.n_outer = 0;
     for (int q = 0; q < n; ++q) {
         bool in_tile = false;
@@ -1174,10 +1223,16 @@ void launch_pass(const EvalCall& call, const TilePlan& plan, size_t k, void* gat
     a.tiles_per_wg = tpw;
     hipLaunchKernelGGL(k_tile_pass, dim3((unsigned)(n_tiles / tpw), C), dim3(kTT), kTileAmps * sizeof(double2),
                        call.stream, st, im.gates + plan.goff[k], im.ops + plan.ooff[k], im.sweeps + plan.soff[k], tab,
-                       mats, a);
+                       pd.mats + (size_t)slot0 * pd.m4(), a);
 }
 
-int launch_gates(const EvalCall& call, const HbmCommon& h, double2* st, double2* tab, void* gate_buf, double2* mats) {
+void launch_all_passes(const EvalCall& call, const PlanDev& pd, double2* st, const double2* tab, int tab_stride,
+                       int slot0, int C) {
+    for (size_t k = 0; k < pd.plan->passes.size(); ++k) launch_pass(call, pd, k, st, tab, tab_stride, slot0, C);
+}
+
+// |0..0>, the angle table and every gate for the h.C instances of a chunk; pd.plan == nullptr: one sweep per gate
+int launch_gates(const EvalCall& call, const HbmCommon& h, double2* st, double2* tab, const PlanDev& pd) {
     const int n = h.n, C = h.C;
     const int64_t D = (int64_t)1 << n;
     const int64_t tot = D * C;
@@ -1187,12 +1242,9 @@ int launch_gates(const EvalCall& call, const HbmCommon& h, double2* st, double2*
     if (na > 0)
         hipLaunchKernelGGL(k_angles, dim3((unsigned)((na + kT - 1) / kT)), dim3(kT), 0, call.stream,
                            h, tab);
-    if (tiled(call) && gate_buf != nullptr) {
-        const TilePlan& plan = plan_of(call);
-        int rc = upload_plan(call, plan, gate_buf);
-        if (rc) return rc;
-        launch_mats(call, plan, gate_buf, tab, mats, C);
-        for (size_t k = 0; k < plan.passes.size(); ++k) launch_pass(call, plan, k, gate_buf, st, tab, mats, C);
+    if (pd.plan) {
+        launch_mats(call, pd, tab, h.n_ops, 0, C);
+        launch_all_passes(call, pd, st, tab, h.n_ops, 0, C);
         VQA_HIP(hipGetLastError());
         return VQA_OK;
     }
@@ -1213,91 +1265,122 @@ int launch_gates(const EvalCall& call, const HbmCommon& h, double2* st, double2*
 
 // Observables and marginal of C states side by side -> output rows e0 .. e0 + C - 1.
 // pair == nullptr: plain expectation values (k_zpart / k_xpart / k_finish).
-// pair != nullptr: the states are the pi-moved states of a sweep, `pair` the unshifted
+// pair != nullptr: the states are the pi-moved states of a sweep, pair->f the unshifted
 // final state; writes the two shifted rows of every parameter (k_*2 kernels).
+// hl.plan != nullptr: the pure-X terms are measured last, as Z-strings behind a layer of
+// Hadamards that is applied to the states in place (plain: to the copy hl.alt of the one
+// state when that is given; pairs: pair->fh is the transformed unshifted state).
 struct PairArgs {
     const double2* f;
+    const double2* fh;
     int64_t row0;
     const int32_t* ord;
     const double* ord_coef;
     double shift;
 };
+struct HLayer {
+    PlanDev pd;
+    uint64_t mask = 0;
+    double2* alt = nullptr;
+};
 
-int measure_states(const EvalCall& call, const double2* st, int C, int64_t e0, int nb, double* partial,
-                   const PairArgs* pair) {
+int measure_states(const EvalCall& call, double2* st, int C, int64_t e0, int nb, double* partial,
+                   const PairArgs* pair, const HLayer& hl) {
     const int n = call.c->n_qubits;
     const int n_obs = call.obs.n_obs;
-    auto zlaunch = [&](const ZBatch& zb, double* out, int stride, int col0, int spread, bool first) {
+    if (n_obs > 0) {
+        const unsigned g = (unsigned)((C * n_obs + kT - 1) / kT);
+        if (pair)
+            hipLaunchKernelGGL(k_out_init2, dim3(g), dim3(kT), 0, call.stream, call.d_out_expect, pair->row0, pair->ord,
+                               pair->ord_coef, pair->shift, C, n_obs);
+        else
+            hipLaunchKernelGGL(k_out_init, dim3(g), dim3(kT), 0, call.stream, call.d_out_expect, e0, C, n_obs, call.spec);
+    }
+    // Z-strings of all observables, kZBatch at a time; `f` = the unshifted state the pairs are taken with
+    auto zflush = [&](ZBatch& zb, const double2* states, const double2* f) {
+        if (zb.nz == 0) return;
         if (pair) {
-            hipLaunchKernelGGL(k_zpart2, dim3(nb, C), dim3(kT), 0, call.stream, pair->f, st, n, zb, partial);
-            hipLaunchKernelGGL(k_finish2, dim3(C), dim3(kT), 0, call.stream, partial, nb, zb.nz, zb, 1, 0.0, out,
-                               pair->row0, pair->ord, pair->ord_coef, pair->shift, stride, col0, spread,
-                               first ? 0 : 1);
+            hipLaunchKernelGGL(k_zpart2, dim3(nb, C), dim3(kT), 0, call.stream, f, states, n, zb, partial);
+            hipLaunchKernelGGL(k_finish2, dim3(C), dim3(kT), 0, call.stream, partial, nb, zb.nz, zb, 1, 0.0,
+                               call.d_out_expect, pair->row0, pair->ord, pair->ord_coef, pair->shift, n_obs, 0, 0);
         } else {
-            hipLaunchKernelGGL(k_zpart, dim3(nb, C), dim3(kT), 0, call.stream, st, n, zb, partial);
-            hipLaunchKernelGGL(k_finish, dim3(C), dim3(kT), 0, call.stream, partial, nb, zb.nz, zb, 1, 0.0, out,
-                               e0, stride, col0, spread, first ? 0 : 1, call.spec);
+            hipLaunchKernelGGL(k_zpart, dim3(nb, C), dim3(kT), 0, call.stream, states, n, zb, partial);
+            hipLaunchKernelGGL(k_finish, dim3(C), dim3(kT), 0, call.stream, partial, nb, zb.nz, zb, 1, 0.0,
+                               call.d_out_expect, e0, n_obs, 0, 0, call.spec);
         }
-    };
-    for (int o = 0; o < n_obs; ++o) {
-        bool first = true;
-        ZBatch zb;
-        zb.marg_bits = 0;
-        zb.m0 = 0;
         zb.nz = 0;
-        auto flush = [&]() {
-            if (zb.nz == 0) return;
-            zlaunch(zb, call.d_out_expect, n_obs, o, 0, first);
-            first = false;
-            zb.nz = 0;
-        };
+    };
+    ZBatch zb;
+    zb.marg_bits = 0;
+    zb.m0 = 0;
+    zb.nz = 0;
+    for (int o = 0; o < n_obs; ++o) {
         for (int t = call.obs.off[o]; t < call.obs.off[o + 1]; ++t) {
-            if (call.obs.x[t] == 0) {
-                zb.z[zb.nz] = call.obs.z[t];
-                zb.coef[zb.nz] = call.obs.coef[t];
-                if (++zb.nz == kZBatch) flush();
-            }
+            if (call.obs.x[t] != 0) continue;
+            zb.z[zb.nz] = call.obs.z[t];
+            zb.coef[zb.nz] = call.obs.coef[t];
+            zb.col[zb.nz] = o;
+            if (++zb.nz == kZBatch) zflush(zb, st, pair ? pair->f : nullptr);
         }
-        flush();
+    }
+    zflush(zb, st, pair ? pair->f : nullptr);
+    // X/Y strings one at a time, except the pure-X ones when the Hadamard layer is in use
+    for (int o = 0; o < n_obs; ++o) {
         for (int t = call.obs.off[o]; t < call.obs.off[o + 1]; ++t) {
-            if (call.obs.x[t] != 0) {
-                if (pair) {
-                    hipLaunchKernelGGL(k_xpart2, dim3(nb, C), dim3(kT), 0, call.stream, pair->f, st, n,
-                                       call.obs.z[t], call.obs.x[t], partial);
-                    hipLaunchKernelGGL(k_finish2, dim3(C), dim3(kT), 0, call.stream, partial, nb, 1, zb, 0,
-                                       call.obs.coef[t], call.d_out_expect, pair->row0, pair->ord,
-                                       pair->ord_coef, pair->shift, n_obs, o, 0, first ? 0 : 1);
-                } else {
-                    hipLaunchKernelGGL(k_xpart, dim3(nb, C), dim3(kT), 0, call.stream, st, n,
-                                       call.obs.z[t], call.obs.x[t], partial);
-                    hipLaunchKernelGGL(k_finish, dim3(C), dim3(kT), 0, call.stream, partial, nb,
-                                       1, zb, 0, call.obs.coef[t], call.d_out_expect, e0, n_obs, o,
-                                       0, first ? 0 : 1, call.spec);
-                }
-                first = false;
+            if (call.obs.x[t] == 0 || (hl.pd.plan && call.obs.z[t] == 0)) continue;
+            if (pair) {
+                hipLaunchKernelGGL(k_xpart2, dim3(nb, C), dim3(kT), 0, call.stream, pair->f, st, n,
+                                   call.obs.z[t], call.obs.x[t], partial);
+                hipLaunchKernelGGL(k_finish2, dim3(C), dim3(kT), 0, call.stream, partial, nb, 1, zb, 0,
+                                   call.obs.coef[t], call.d_out_expect, pair->row0, pair->ord,
+                                   pair->ord_coef, pair->shift, n_obs, o, 0);
+            } else {
+                hipLaunchKernelGGL(k_xpart, dim3(nb, C), dim3(kT), 0, call.stream, st, n,
+                                   call.obs.z[t], call.obs.x[t], partial);
+                hipLaunchKernelGGL(k_finish, dim3(C), dim3(kT), 0, call.stream, partial, nb,
+                                   1, zb, 0, call.obs.coef[t], call.d_out_expect, e0, n_obs, o, 0, call.spec);
             }
-        }
-        if (first) {  // observable without terms: expectation 0
-            ZBatch z0;
-            z0.nz = 0; z0.marg_bits = 0; z0.m0 = 0;
-            zlaunch(z0, call.d_out_expect, n_obs, o, 0, true);
         }
     }
     if (call.n_marg_bits > 0) {
         const int M = 1 << call.n_marg_bits;
         for (int m0 = 0; m0 < M; m0 += kZBatch) {
-            ZBatch zb;
-            zb.marg_bits = call.n_marg_bits;
-            zb.m0 = m0;
-            zb.nz = std::min(kZBatch, M - m0);
+            ZBatch mb;
+            mb.marg_bits = call.n_marg_bits;
+            mb.m0 = m0;
+            mb.nz = std::min(kZBatch, M - m0);
             if (pair) {
-                zlaunch(zb, call.d_out_marginal, M, m0, 1, true);
+                hipLaunchKernelGGL(k_zpart2, dim3(nb, C), dim3(kT), 0, call.stream, pair->f, st, n, mb, partial);
+                hipLaunchKernelGGL(k_finish2, dim3(C), dim3(kT), 0, call.stream, partial, nb, mb.nz, mb, 1, 0.0,
+                                   call.d_out_marginal, pair->row0, pair->ord, pair->ord_coef, pair->shift, M, m0, 1);
             } else {
-                hipLaunchKernelGGL(k_zpart, dim3(nb, C), dim3(kT), 0, call.stream, st, n, zb, partial);
-                hipLaunchKernelGGL(k_finish, dim3(C), dim3(kT), 0, call.stream, partial, nb, zb.nz, zb, 0, 0.0,
-                                   call.d_out_marginal, e0, M, m0, 1, 0, call.spec);
+                hipLaunchKernelGGL(k_zpart, dim3(nb, C), dim3(kT), 0, call.stream, st, n, mb, partial);
+                hipLaunchKernelGGL(k_finish, dim3(C), dim3(kT), 0, call.stream, partial, nb, mb.nz, mb, 0, 0.0,
+                                   call.d_out_marginal, e0, M, m0, 1, call.spec);
             }
         }
+    }
+    if (hl.pd.plan) {
+        // H X H = Z: behind the Hadamard layer the pure-X strings are Z-strings with z = x
+        double2* hs = st;
+        if (!pair && hl.alt) {
+            const int64_t D = (int64_t)1 << n;
+            hipLaunchKernelGGL(k_spawn, dim3((unsigned)((D + kT - 1) / kT)), dim3(kT), 0, call.stream, hl.alt, st, D, 1);
+            hs = hl.alt;
+        }
+        launch_mats(call, hl.pd, nullptr, 0, 0, C);
+        launch_all_passes(call, hl.pd, hs, nullptr, 0, 0, C);
+        zb.nz = 0;
+        for (int o = 0; o < n_obs; ++o) {
+            for (int t = call.obs.off[o]; t < call.obs.off[o + 1]; ++t) {
+                if (call.obs.x[t] == 0 || call.obs.z[t] != 0) continue;
+                zb.z[zb.nz] = call.obs.x[t];
+                zb.coef[zb.nz] = call.obs.coef[t];
+                zb.col[zb.nz] = o;
+                if (++zb.nz == kZBatch) zflush(zb, hs, pair ? pair->fh : nullptr);
+            }
+        }
+        zflush(zb, hs, pair ? pair->fh : nullptr);
     }
     VQA_HIP(hipGetLastError());
     return VQA_OK;
@@ -1319,6 +1402,13 @@ static int chunk_plan(const EvalCall& call, double frac, size_t cap_bytes, int64
     return VQA_OK;
 }
 
+// carves a workspace: every part 256-byte aligned
+struct Carver {
+    char* p = nullptr;
+    size_t total = 0;
+    size_t add(size_t bytes) { const size_t at = total; total += pad256(bytes); return at; }
+};
+
 int hbm_engine_run(const EvalCall& call) {
     const int n = call.c->n_qubits;
     if (n < 1 || n > 30) VQA_FAIL(VQA_EUNSUPPORTED, "HBM engine supports 1..30 qubits (got %d)", n);
@@ -1331,20 +1421,44 @@ int hbm_engine_run(const EvalCall& call) {
     int rc = chunk_plan(call, 0.4, (size_t)8 << 30, Cmax, nb);
     if (rc) return rc;
     Cmax = std::min<int64_t>(Cmax, call.E);
-    const size_t st_bytes = (size_t)Cmax * D * sizeof(double2);
-    const size_t tab_bytes = ((size_t)Cmax * std::max(call.c->n_ops, 1) * sizeof(double2) + 255) & ~(size_t)255;
-    const size_t part_bytes = ((size_t)Cmax * nb * kZBatch * sizeof(double) + 255) & ~(size_t)255;
-    const size_t gate_bytes = gate_buf_bytes(call);
-    const size_t mat_bytes = mats_bytes(call, Cmax);
+    PlanDev pd;
+    HLayer hl;
+    if (tiled(call)) {
+        pd.plan = &plan_of(call);
+        pd.g = (size_t)call.c->n_ops;
+        hl.mask = hlayer_mask(call);
+        if (hl.mask) {
+            hl.pd.plan = &hplan_of(call, hl.mask);
+            hl.pd.g = kHGates;
+        }
+    }
+    Carver cv;
+    const size_t o_st = cv.add((size_t)Cmax * D * sizeof(double2));
+    const size_t o_tab = cv.add((size_t)Cmax * std::max(call.c->n_ops, 1) * sizeof(double2));
+    const size_t o_part = cv.add((size_t)Cmax * nb * kZBatch * sizeof(double));
+    const size_t o_gate = cv.add(pd.plan ? gate_buf_bytes(pd.g) : 0);
+    const size_t o_mats = cv.add(pd.plan ? pd.mats_bytes(Cmax) : 0);
+    const size_t o_hgate = cv.add(hl.pd.plan ? gate_buf_bytes(hl.pd.g) : 0);
+    const size_t o_hmats = cv.add(hl.pd.plan ? hl.pd.mats_bytes(Cmax) : 0);
     void* ws = nullptr;
-    rc = workspace_get(call.device, st_bytes + tab_bytes + part_bytes + gate_bytes + mat_bytes, &ws);
+    rc = workspace_get(call.device, cv.total, &ws);
     if (rc) return rc;
-    double2* st = (double2*)ws;
-    double2* tab = (double2*)((char*)ws + st_bytes);
-    double* partial = (double*)((char*)ws + st_bytes + tab_bytes);
-    void* gate_buf = (char*)ws + st_bytes + tab_bytes + part_bytes;
-    double2* mats = (double2*)((char*)gate_buf + gate_bytes);
-
+    char* w = (char*)ws;
+    double2* st = (double2*)(w + o_st);
+    double2* tab = (double2*)(w + o_tab);
+    double* partial = (double*)(w + o_part);
+    if (pd.plan) {
+        pd.buf = w + o_gate;
+        pd.mats = (double2*)(w + o_mats);
+        rc = upload_plan(call, pd);
+        if (rc) return rc;
+    }
+    if (hl.pd.plan) {
+        hl.pd.buf = w + o_hgate;
+        hl.pd.mats = (double2*)(w + o_hmats);
+        rc = upload_plan(call, hl.pd);
+        if (rc) return rc;
+    }
     for (int64_t e0 = 0; e0 < call.E; e0 += Cmax) {
         HbmCommon h;
         h.n = n;
@@ -1356,9 +1470,9 @@ int hbm_engine_run(const EvalCall& call) {
         h.spec = call.spec;
         h.e_base = e0;
         h.C = (int)std::min<int64_t>(Cmax, call.E - e0);
-        rc = launch_gates(call, h, st, tab, gate_buf, mats);
+        rc = launch_gates(call, h, st, tab, pd);
         if (rc) return rc;
-        rc = measure_states(call, st, h.C, e0, nb, partial, nullptr);
+        rc = measure_states(call, st, h.C, e0, nb, partial, nullptr, hl);   // the chunk's states are not needed afterwards
         if (rc) return rc;
     }
     return VQA_OK;
@@ -1375,42 +1489,59 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
     if (n > 30) VQA_FAIL(VQA_EUNSUPPORTED, "HBM engine supports 1..30 qubits (got %d)", n);
     if (call.n_marg_bits > 10)
         VQA_FAIL(VQA_EUNSUPPORTED, "HBM engine: n_marg_bits <= 10 (got %d)", call.n_marg_bits);
-    const TilePlan& plan = plan_of(call);
+    PlanDev pd;
+    pd.plan = &plan_of(call);
+    pd.g = (size_t)call.c->n_ops;
+    const TilePlan& plan = *pd.plan;
+    HLayer hl;
+    hl.mask = hlayer_mask(call);
+    if (hl.mask) {
+        hl.pd.plan = &hplan_of(call, hl.mask);
+        hl.pd.g = kHGates;
+    }
     const int64_t D = (int64_t)1 << n;
     const int P = call.c->n_theta, K = 2 * P + 1;
     const int m = (int)plan.ord.size(), n_unused = (int)plan.unused.size();
     const int n_ops = std::max(call.c->n_ops, 1);
     int64_t Cmax;
     int nb;
-    // slot 0: unshifted final state, slot 1: running unshifted state, slots 2..: one per parameter
+    // slot 0: unshifted final state, slot 1: running unshifted state, slots 2 ..: one per parameter,
+    // behind them the unshifted final state with the Hadamard layer applied (when in use)
     int rc = chunk_plan(call, 0.6, (size_t)200 << 30, Cmax, nb);
     if (rc) return rc;
-    if (Cmax < 3) VQA_FAIL(VQA_ENOMEM, "not enough free device memory for three %d-qubit states", n);
-    const int C = (int)std::min<int64_t>(Cmax - 2, std::max(m, 1));
-    auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    const size_t st_bytes = (size_t)(C + 2) * D * sizeof(double2);
-    const size_t tab_bytes = pad((size_t)(C + 2) * n_ops * sizeof(double2));
-    const size_t part_bytes = pad((size_t)C * nb * kZBatch * 2 * sizeof(double));
-    const size_t gate_bytes = pad(gate_buf_bytes(call));
-    const size_t ord_bytes = pad((size_t)std::max(m, 1) * sizeof(int32_t));
-    const size_t coef_bytes = pad((size_t)std::max(m, 1) * sizeof(double));
-    const size_t unused_bytes = pad((size_t)std::max(n_unused, 1) * sizeof(int32_t));
-    const size_t mat_bytes = mats_bytes(call, C + 2);
-    const size_t M4 = std::max<size_t>(plan.all_mats.size(), 1) * 4;   // double2 per instance in the matrix table
+    if (Cmax < 4) VQA_FAIL(VQA_ENOMEM, "not enough free device memory for four %d-qubit states", n);
+    const int C = (int)std::min<int64_t>(Cmax - 3, std::max(m, 1));
+    Carver cv;
+    const size_t o_st = cv.add((size_t)(C + 3) * D * sizeof(double2));
+    const size_t o_tab = cv.add((size_t)(C + 2) * n_ops * sizeof(double2));
+    const size_t o_part = cv.add((size_t)C * nb * kZBatch * 2 * sizeof(double));
+    const size_t o_gate = cv.add(gate_buf_bytes(pd.g));
+    const size_t o_mats = cv.add(pd.mats_bytes(C + 2));
+    const size_t o_ord = cv.add((size_t)std::max(m, 1) * sizeof(int32_t));
+    const size_t o_coef = cv.add((size_t)std::max(m, 1) * sizeof(double));
+    const size_t o_unused = cv.add((size_t)std::max(n_unused, 1) * sizeof(int32_t));
+    const size_t o_hgate = cv.add(hl.pd.plan ? gate_buf_bytes(hl.pd.g) : 0);
+    const size_t o_hmats = cv.add(hl.pd.plan ? hl.pd.mats_bytes(C) : 0);
     void* ws = nullptr;
-    rc = workspace_get(call.device, st_bytes + tab_bytes + part_bytes + gate_bytes + ord_bytes + coef_bytes + unused_bytes + mat_bytes, &ws);
+    rc = workspace_get(call.device, cv.total, &ws);
     if (rc) return rc;
     char* w = (char*)ws;
-    double2* st = (double2*)w;                 w += st_bytes;
-    double2* tab = (double2*)w;                w += tab_bytes;
-    double* partial = (double*)w;              w += part_bytes;
-    void* gate_buf = w;                        w += gate_bytes;
-    int32_t* d_ord = (int32_t*)w;              w += ord_bytes;
-    double* d_coef = (double*)w;               w += coef_bytes;
-    int32_t* d_unused = (int32_t*)w;           w += unused_bytes;
-    double2* mats = (double2*)w;
-    rc = upload_plan(call, plan, gate_buf);
+    double2* st = (double2*)(w + o_st);
+    double2* tab = (double2*)(w + o_tab);
+    double* partial = (double*)(w + o_part);
+    int32_t* d_ord = (int32_t*)(w + o_ord);
+    double* d_coef = (double*)(w + o_coef);
+    int32_t* d_unused = (int32_t*)(w + o_unused);
+    pd.buf = w + o_gate;
+    pd.mats = (double2*)(w + o_mats);
+    rc = upload_plan(call, pd);
     if (rc) return rc;
+    if (hl.pd.plan) {
+        hl.pd.buf = w + o_hgate;
+        hl.pd.mats = (double2*)(w + o_hmats);
+        rc = upload_plan(call, hl.pd);
+        if (rc) return rc;
+    }
     if (m > 0) {
         VQA_HIP(hipMemcpyAsync(d_ord, plan.ord.data(), (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, call.stream));
         VQA_HIP(hipMemcpyAsync(d_coef, plan.ord_coef.data(), (size_t)m * sizeof(double), hipMemcpyHostToDevice, call.stream));
@@ -1421,6 +1552,7 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
     double2* F = st;
     double2* R = st + D;
     double2* S = st + 2 * D;
+    hl.alt = st + (int64_t)(C + 2) * D;   // the unshifted final state behind the Hadamard layer
     const unsigned gD = (unsigned)((D + kT - 1) / kT);
     HbmCommon h;
     h.n = n;
@@ -1438,9 +1570,9 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
         hipLaunchKernelGGL(k_init, dim3(gD), dim3(kT), 0, call.stream, F, D, D);
         if (h.n_ops > 0)
             hipLaunchKernelGGL(k_angles, dim3((unsigned)((h.n_ops + kT - 1) / kT)), dim3(kT), 0, call.stream, h, tab);
-        launch_mats(call, plan, gate_buf, tab, mats, 1);
-        for (size_t k = 0; k < n_pass; ++k) launch_pass(call, plan, k, gate_buf, F, tab, mats, 1);
-        rc = measure_states(call, F, 1, row0, nb, partial, nullptr);
+        launch_mats(call, pd, tab, h.n_ops, 0, 1);
+        launch_all_passes(call, pd, F, tab, h.n_ops, 0, 1);
+        rc = measure_states(call, F, 1, row0, nb, partial, nullptr, hl);   // leaves F alone: the layer goes onto hl.alt
         if (rc) return rc;
         if (n_unused > 0) {
             if (call.obs.n_obs > 0)
@@ -1462,8 +1594,8 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
             const int64_t na = (int64_t)(cnt + 2) * h.n_ops;
             hipLaunchKernelGGL(k_sweep_angles, dim3((unsigned)((na + kT - 1) / kT)), dim3(kT), 0, call.stream, h, j,
                                d_ord + a, cnt + 2, tab);
-            launch_mats(call, plan, gate_buf, tab, mats, cnt + 2);
-            for (; rpass < k0; ++rpass) launch_pass(call, plan, rpass, gate_buf, R, tab + n_ops, mats + M4, 1);
+            launch_mats(call, pd, tab, h.n_ops, 0, cnt + 2);
+            for (; rpass < k0; ++rpass) launch_pass(call, pd, rpass, R, tab + n_ops, h.n_ops, 1, 1);
             int live = 0;
             for (size_t k = k0; k < n_pass; ++k) {
                 int fresh = 0;
@@ -1473,14 +1605,14 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
                 live += fresh;
                 if (k < k1) {
                     // the running state moves on with the chunk while later passes still take copies of it
-                    launch_pass(call, plan, k, gate_buf, R, tab + n_ops, mats + M4, live + 1);
+                    launch_pass(call, pd, k, R, tab + n_ops, h.n_ops, 1, live + 1);
                     rpass = k + 1;
                 } else {
-                    launch_pass(call, plan, k, gate_buf, S, tab + 2 * (size_t)n_ops, mats + 2 * M4, live);
+                    launch_pass(call, pd, k, S, tab + 2 * (size_t)n_ops, h.n_ops, 2, live);
                 }
             }
-            PairArgs pa = { F, row0, d_ord + a, d_coef + a, call.spec.shift };
-            rc = measure_states(call, S, cnt, 0, nb, partial, &pa);
+            PairArgs pa = { F, hl.alt, row0, d_ord + a, d_coef + a, call.spec.shift };
+            rc = measure_states(call, S, cnt, 0, nb, partial, &pa, hl);
             if (rc) return rc;
         }
     }
@@ -1491,11 +1623,25 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
 int hbm_engine_statevector(const EvalCall& call, double* d_out_state) {
     const int n = call.c->n_qubits;
     if (n < 1 || n > 30) VQA_FAIL(VQA_EUNSUPPORTED, "HBM engine supports 1..30 qubits (got %d)", n);
-    const size_t tab_bytes = ((size_t)std::max(call.c->n_ops, 1) * sizeof(double2) + 255) & ~(size_t)255;
-    const size_t gate_bytes = gate_buf_bytes(call);
+    PlanDev pd;
+    if (tiled(call)) {
+        pd.plan = &plan_of(call);
+        pd.g = (size_t)call.c->n_ops;
+    }
+    Carver cv;
+    const size_t o_tab = cv.add((size_t)std::max(call.c->n_ops, 1) * sizeof(double2));
+    const size_t o_gate = cv.add(pd.plan ? gate_buf_bytes(pd.g) : 0);
+    const size_t o_mats = cv.add(pd.plan ? pd.mats_bytes(1) : 0);
     void* ws = nullptr;
-    int rc = workspace_get(call.device, tab_bytes + gate_bytes + mats_bytes(call, 1), &ws);
+    int rc = workspace_get(call.device, cv.total, &ws);
     if (rc) return rc;
+    char* w = (char*)ws;
+    if (pd.plan) {
+        pd.buf = w + o_gate;
+        pd.mats = (double2*)(w + o_mats);
+        rc = upload_plan(call, pd);
+        if (rc) return rc;
+    }
     HbmCommon h;
     h.n = n;
     h.n_ops = call.c->n_ops;
@@ -1506,8 +1652,7 @@ int hbm_engine_statevector(const EvalCall& call, double* d_out_state) {
     h.spec = call.spec;
     h.e_base = 0;
     h.C = 1;
-    return launch_gates(call, h, (double2*)d_out_state, (double2*)ws, (char*)ws + tab_bytes,
-                        (double2*)((char*)ws + tab_bytes + gate_bytes));
+    return launch_gates(call, h, (double2*)d_out_state, (double2*)(w + o_tab), pd);
 }
 
 }  // namespace vqa

@@ -123,6 +123,7 @@ struct vqa_circuit {
     std::vector<vqa_op> ops;
     std::shared_ptr<vqa::RegProgram> reg;  // host copy of the engine-2 program (may be null)
     std::shared_ptr<void> hbm_plan;        // engine 3: the gate list cut into tiled passes (built on first use)
+    std::map<uint64_t, std::shared_ptr<void>> hbm_hplans;   // engine 3: Hadamard layers used to measure X-type terms, by qubit mask
     std::mutex mu;
     std::map<int, vqa::DeviceCtx> dev;
 };
