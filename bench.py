@@ -79,6 +79,12 @@ def main():
     import torch
     import torch.distributed as dist
 
+    if os.environ.get("VQA_BENCH_WATCHDOG"):
+        # rehearsals: Python stacks of every thread, then exit, if the run is still going after this many seconds
+        import faulthandler
+
+        faulthandler.dump_traceback_later(float(os.environ["VQA_BENCH_WATCHDOG"]), exit=True)
+
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -174,7 +180,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
@@ -256,7 +262,11 @@ def roofline(bytes_alg, flops_alg, evals, kern_ms, measured):
     gbs = bytes_alg * per_s / 1e9
     r = {
         "kernel": "k_reg_psr",
-        "bound": "fp64_valu",
+        # the compute roofline of the dtype: on gfx950 the FP64 MFMA peak equals the FP64 vector
+        # peak (78.6 TFLOP/s); the kernel issues vector FMAs, not MFMA (see bound_detail)
+        "bound": "mfma",
+        "bound_detail": "fp64 compute: vector-ALU FMAs (rocprof: VALU issue-bound), priced at the 78.6 TFLOP/s "
+                        "FP64 peak that MFMA and VALU share on gfx950; state vectors live in registers/LDS",
         "achieved": tflops,
         "peak": FP64_PEAK_TFLOPS,
         "unit": "TFLOP/s",

@@ -35,6 +35,21 @@ def mse_gradient_sums(e, y, w):
     return torch.cat([circ, scale.reshape(1)])
 
 
+def all_reduce_sum(t, group=None):
+    """In-place sum over the ranks of `group`.  RCCL reduces device tensors where they are; the gloo
+    backend (CPU rehearsals and tests) gets a host copy: its path for device tensors stages through
+    pinned buffers per call and is slower than the kernel it follows by orders of magnitude."""
+    import torch.distributed as dist
+
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        h = t.cpu()
+        dist.all_reduce(h, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, group=group)
+    return t
+
+
 def sharded_mse_gradient(circuit, theta, inputs, y, w, obs, n_global=None, group=None, out_expect=None):
     """Exact MSE gradient of the regressor over a mini-batch that is sharded across
     the ranks of `group`: `inputs` / `y` are THIS rank's samples.  Returns the
@@ -53,8 +68,8 @@ def sharded_mse_gradient(circuit, theta, inputs, y, w, obs, n_global=None, group
     if n_global is None:
         count = torch.tensor([float(e.shape[0])], dtype=torch.float64, device=e.device)
         if distributed:
-            dist.all_reduce(count, group=group)
+            all_reduce_sum(count, group=group)
         n_global = float(count.item())
     if distributed:
-        dist.all_reduce(sums, group=group)
+        all_reduce_sum(sums, group=group)
     return sums / n_global
