@@ -195,6 +195,26 @@ int vqa_psr_full_dev(vqa_circuit* c, int device, void* stream,
                      double* d_out_expect, double* d_out_marginal);
 
 /*
+ * Shot sampling.  For each of E rows draws counts[e, 0..n_outcomes) ~ Multinomial(shots[e],
+ * probs[e, :]) (row-major; a row of probs is used as given, its last entry takes what the
+ * others leave; negative or NaN entries count as 0).  With probs = the marginal of the
+ * lowest one or two qubits (out_marginal above) this replaces state.sampling(n_shots)
+ * followed by `samples % 2` / `samples % 4` and the bincount
+ * (vqa/QNN/myQNNs_base.py:725-727, 749-765; vqa/QNN/myQNNs_classifier.py:559, 613-621,
+ * 640-649): the reference keeps nothing else of its samples.  The stream of random numbers
+ * is Philox-4x32-10 keyed by `seed`; row e of a call draws from counter (e, stream_id), so
+ * results do not depend on the launch shape, and calls with different stream_id are
+ * independent.  qulacs' own generator cannot be reproduced: agreement with the reference
+ * is in distribution.  _dev: device pointers, queued on `stream`, not waited for.
+ */
+int vqa_sample_counts(int device, const double* probs, int n_outcomes,
+                      const int64_t* shots, int64_t E, uint64_t seed, uint64_t stream_id,
+                      int64_t* counts);
+int vqa_sample_counts_dev(int device, void* stream, const double* d_probs, int n_outcomes,
+                          const int64_t* d_shots, int64_t E, uint64_t seed, uint64_t stream_id,
+                          int64_t* d_counts);
+
+/*
  * Final state of ONE instance, interleaved (re, im) doubles, 2 * 2^n values,
  * host pointer.  For plumbing tests of the per-sample circuit.run(x) shim
  * (vqa/QNN/myQNNs_base.py:913); not a hot-path call.

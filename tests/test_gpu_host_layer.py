@@ -120,6 +120,30 @@ def test_device_statistics_clt_gradient():
     assert np.max(np.abs(gd2 - ex2)) < 5e-3
 
 
+def test_device_statistics_sampled_gradient():
+    """Finite-shot gradient with the outcome counts drawn on the GPU (device sampler): the host
+    path's counters and shot totals, an unbiased estimate of the exact gradient (mean of repeated
+    draws), and its scatter as the host path's."""
+    (g, p), (o, _) = pair(create_ibm_HEA_ansatz, 6, 2, myQNN_base, n_train=32)
+    g.device_statistics = True
+    g.min_approx_shots = o.min_approx_shots = -1
+    shots = np.full(g.n_params, 400)
+    N = len(g.x_train)
+    np.random.seed(3)
+    g.MSE_grad_eval(p, shots, mini_batch_size=N)
+    np.random.seed(3)
+    o.MSE_grad_eval(p, shots, mini_batch_size=N)
+    assert (g.shots_counter[0], g.call_counter[0], g.circuit_counter[0]) == \
+           (o.shots_counter[0], o.call_counter[0], o.circuit_counter[0])
+    exact = o.MSE_grad_eval(p, shots, mini_batch_size=N, option_min_approx=-10)
+    R = 60
+    gd = np.array([g.MSE_grad_eval(p, shots, mini_batch_size=N) for _ in range(R)])
+    gh = np.array([o.MSE_grad_eval(p, shots, mini_batch_size=N) for _ in range(R)])
+    sd = gh.std(axis=0) + 1e-12
+    assert np.max(np.abs(gd.mean(axis=0) - exact) / sd) < 6 / np.sqrt(R) * 1.5
+    assert np.all(gd.std(axis=0) < 1.8 * sd) and np.all(gd.std(axis=0) > sd / 1.8)
+
+
 def test_pauli_sum_target_matches_oracle_circuit():
     from test_vqe_target import make
     vg, p = make(n=10, d=3, min_approx=-10, cls=LearningCircuit)

@@ -14,5 +14,6 @@ from .qnn_base import myQNN_base, myQNN_regression  # noqa: F401
 from .qnn_classifier import myQNN_classifier  # noqa: F401
 from .vqe_target import PauliSumVQE  # noqa: F401
 from . import optimizers  # noqa: F401
+from .sampling import sample_counts, sample_z_means  # noqa: F401
 
 __version__ = "0.1.0"

@@ -441,6 +441,42 @@ int vqa_psr_full(vqa_circuit* c, int device, const double* theta, const double* 
     return VQA_OK;
 }
 
+int vqa_sample_counts_dev(int device, void* stream, const double* d_probs, int n_outcomes,
+                          const int64_t* d_shots, int64_t E, uint64_t seed, uint64_t stream_id,
+                          int64_t* d_counts) {
+    if (n_outcomes < 1 || n_outcomes > 1024) VQA_FAIL(VQA_EINVAL, "n_outcomes must be in [1, 1024] (got %d)", n_outcomes);
+    if (E < 0) VQA_FAIL(VQA_EINVAL, "E must be >= 0");
+    if (E == 0) return VQA_OK;
+    if (!d_probs || !d_shots || !d_counts) VQA_FAIL(VQA_EINVAL, "probs, shots and counts must not be NULL");
+    DeviceState* ds;
+    int rc = device_state(device, &ds);
+    if (rc) return rc;
+    VQA_HIP(hipSetDevice(device));
+    return sample_counts_launch((hipStream_t)stream, d_probs, n_outcomes, d_shots, E, seed, stream_id, d_counts);
+}
+
+int vqa_sample_counts(int device, const double* probs, int n_outcomes, const int64_t* shots, int64_t E,
+                      uint64_t seed, uint64_t stream_id, int64_t* counts) {
+    if (n_outcomes < 1 || n_outcomes > 1024) VQA_FAIL(VQA_EINVAL, "n_outcomes must be in [1, 1024] (got %d)", n_outcomes);
+    if (E < 0) VQA_FAIL(VQA_EINVAL, "E must be >= 0");
+    if (E == 0) return VQA_OK;
+    if (!probs || !shots || !counts) VQA_FAIL(VQA_EINVAL, "probs, shots and counts must not be NULL");
+    DeviceState* ds;
+    int rc = device_state(device, &ds);
+    if (rc) return rc;
+    VQA_HIP(hipSetDevice(device));
+    hipStream_t s = ds->stream;
+    DevBuf dp, dn, dc;
+    if ((rc = dp.upload(probs, (size_t)E * n_outcomes * 8, s))) return rc;
+    if ((rc = dn.upload(shots, (size_t)E * 8, s))) return rc;
+    if ((rc = dc.alloc((size_t)E * n_outcomes * 8))) return rc;
+    rc = sample_counts_launch(s, (const double*)dp.p, n_outcomes, (const int64_t*)dn.p, E, seed, stream_id, (int64_t*)dc.p);
+    if (rc) { (void)hipStreamSynchronize(s); return rc; }
+    VQA_HIP(hipMemcpyAsync(counts, dc.p, (size_t)E * n_outcomes * 8, hipMemcpyDeviceToHost, s));
+    VQA_HIP(hipStreamSynchronize(s));
+    return VQA_OK;
+}
+
 int vqa_statevector(vqa_circuit* c, int device, const double* theta, const double* input_row,
                     int shift_param, double shift_val, double* out_state) {
     if (!c) VQA_FAIL(VQA_EINVAL, "circuit handle is NULL");

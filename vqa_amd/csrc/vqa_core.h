@@ -157,6 +157,10 @@ bool hbm_engine_can_sweep(const EvalCall& call);
 int hbm_engine_sweep(const EvalCall& call, int n_samples);
 int hbm_engine_statevector(const EvalCall& call, double* d_out_state);
 
+// multinomial outcome counts per row, chain of binomials (kern_sample.hip)
+int sample_counts_launch(hipStream_t stream, const double* d_probs, int M, const int64_t* d_shots, int64_t E,
+                         uint64_t seed, uint64_t stream_id, int64_t* d_counts);
+
 // per-device workspace owned by the library (grown on demand, never shrunk)
 int workspace_get(int device, size_t bytes, void** out);
 

@@ -525,8 +525,8 @@ class myQNN_base:
             # expectation values are (on the GPU with the HIP circuit) and only the
             # gradient and the unshifted values come back
             return self._exact_grad(params, eval_ind, y_eval)
-        if getattr(self, "device_statistics", False) and min_approx >= 0:
-            g = self._clt_grad_on_device(params, n_shots_list, wt_dist, eval_ind, y_eval, min_approx)
+        if getattr(self, "device_statistics", False):
+            g = self._grad_on_device(params, n_shots_list, wt_dist, eval_ind, y_eval, min_approx)
             if g is not None:
                 return g
         E = self._psr_all(params, eval_ind)
@@ -570,12 +570,22 @@ class myQNN_base:
         out[:] = grad
         return out
 
-    def _clt_grad_on_device(self, params, n_shots_list, wt_dist, eval_ind, y_eval, min_approx):
-        """MSE_grad_eval when every estimate is in the CLT branch (n >= min_approx_shots,
-        myQNNs_base.py:892-905), computed where the expectation values are.  None when the
-        circuit does not compute on a GPU or some shot count falls below the threshold."""
+    def _grad_on_device(self, params, n_shots_list, wt_dist, eval_ind, y_eval, min_approx):
+        """MSE_grad_eval with the per-instance statistics taken where the expectation values are:
+        either every estimate in the CLT branch (n >= min_approx_shots >= 0, myQNNs_base.py:892-905:
+        normal deviates from a torch generator seeded from NumPy's) or every estimate sampled
+        (min_approx_shots < 0 or n below it, myQNNs_base.py:715-738: binomial outcome counts from the
+        library's device sampler, seeded from NumPy's).  Same estimators, counters and shot totals as
+        the host path; the random streams differ from it.  None when the circuit does not compute on
+        a GPU or the batch mixes the two branches."""
         n_all = np.floor(np.asarray(n_shots_list, dtype=float)[:, None] * wt_dist[None, :])   # [P+1, B]
-        if n_all.min() < max(min_approx, 2):
+        if n_all.min() < 2:
+            return None
+        if min_approx >= 0 and n_all.min() >= min_approx:
+            sampled = False
+        elif min_approx < 0 or n_all.max() < min_approx:
+            sampled = True
+        else:
             return None
         E = self._psr_all(params, eval_ind, keep_on_device=True)
         if not hasattr(E, "detach"):
@@ -584,8 +594,7 @@ class myQNN_base:
 
         B, K = int(E.shape[0]), int(E.shape[1])
         P = self.n_c_params
-        gen = torch.Generator(device=E.device)
-        gen.manual_seed(int(np.random.randint(0, 2 ** 31 - 1)))
+        seed = int(np.random.randint(0, 2 ** 31 - 1))
         w = float(params[-1])
         y = torch.from_numpy(np.ascontiguousarray(y_eval, dtype=np.float64)).to(E.device)
         n = torch.from_numpy(n_all).to(E.device)                        # [P+1, B]
@@ -593,7 +602,14 @@ class myQNN_base:
         n_inst[:, 0] = n[-1]
         n_inst[:, 1::2] = n[:P].T
         n_inst[:, 2::2] = n[:P].T
-        M = E + torch.randn((B, K), dtype=torch.float64, device=E.device, generator=gen) * torch.sqrt((1.0 - E * E) / n_inst)
+        if sampled:
+            from .sampling import sample_z_means
+
+            M = sample_z_means(E, n_inst.to(torch.int64), seed)
+        else:
+            gen = torch.Generator(device=E.device)
+            gen.manual_seed(seed)
+            M = E + torch.randn((B, K), dtype=torch.float64, device=E.device, generator=gen) * torch.sqrt((1.0 - E * E) / n_inst)
         M0 = M[:, 0]
         n0 = n[-1]
         M0sq = (n0 / (n0 - 1.0)) * M0 * M0 - 1.0 / (n0 - 1.0)           # unbiased square, myQNNs_base.py:843
@@ -602,7 +618,7 @@ class myQNN_base:
         grad[:P] = (resid[:, None] * (M[:, 1::2] - M[:, 2::2])).mean(0)
         grad[P] = (2.0 * (-y * M0 + w * M0sq)).mean()
         self.circuit_counter[0] += B * K
-        self.call_counter[0] += B * K
+        self.call_counter[0] += (2 if sampled else 1) * B * K           # a sampled state counts twice (myQNNs_base.py:722, 1033)
         self.shots_counter[0] += int(n_all[-1].sum() + 2 * n_all[:P].sum())
         self.cache_train_pred = (w * M0).cpu().numpy()
         self.cache_y_train_eval = y_eval
