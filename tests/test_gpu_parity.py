@@ -218,6 +218,61 @@ def test_headline_sweep_against_explicit_list_and_oracle():
     assert np.abs(m.reshape(B * K, 4)[pick] - want_m).max() < TOL
 
 
+def test_headline_full_batch_properties():
+    """The benchmark's full size (65536 samples x 793 instances): size-independent properties of
+    every instance -- probabilities sum to one, <Z0> equals the signed sum of the marginal, the
+    unshifted column does not depend on the batch around it -- and a seeded subset against the oracle."""
+    import torch
+
+    c = create_ibm_HEA_ansatz(12, 10, seed=0)
+    rng = np.random.default_rng(2)
+    B = 65536
+    x = rng.uniform(0, np.pi, (B, 12))
+    theta = np.random.default_rng(0).uniform(0, 2 * np.pi, c.n_theta)
+    d_in = c.upload_inputs(x)
+    z0 = Observable(12); z0.add_operator(1.0, "Z 0")
+    e, m = c.psr_full(theta, d_in, n_sel=B, obs_list=[z0], n_marg_bits=2)
+    assert bool(torch.isfinite(e).all()) and bool(torch.isfinite(m).all())
+    assert float((m.sum(dim=2) - 1).abs().max()) < TOL
+    assert float((e[:, :, 0] - (m[:, :, 0] - m[:, :, 1] + m[:, :, 2] - m[:, :, 3])).abs().max()) < TOL
+    assert float(m.min()) > -TOL
+    sub = np.sort(rng.choice(B, 40, replace=False)).astype(np.int32)
+    e2, _ = c.psr_full(theta, d_in, sel=sub, obs_list=[z0])
+    assert float((e2 - e[torch.from_numpy(sub.astype(np.int64)).cuda()]).abs().max()) < TOL
+    K = 2 * c.n_theta + 1
+    si, sp, sv = cpu_oracle.psr_lists(len(sub), c.n_theta, sel=sub)
+    pick = rng.choice(len(si), 200, replace=False)
+    want, _ = cpu_oracle.eval_batch(c, theta, c.input_angles(x), si[pick], sp[pick], sv[pick], obs_list=obs_tuples([z0]))
+    assert np.abs(e2.cpu().numpy().reshape(len(sub) * K, 1)[pick] - want).max() < TOL
+
+
+def test_twenty_qubit_sweep_against_explicit_list():
+    """The 20-qubit configuration's circuit (depth 8, 900 gates, 540 parameters): the streaming
+    engine's full sweep of one sample against its explicit-list form on a seeded subset of the 1081
+    instances, the parameter-shift identity against a central difference, and normalisation."""
+    c = create_ibm_HEA_ansatz(20, 8, seed=0)
+    rng = np.random.default_rng(3)
+    theta = rng.uniform(0, 2 * np.pi, c.n_theta)
+    x = rng.uniform(0, np.pi, (1, 20))
+    d_in = c.upload_inputs(x)
+    z0 = Observable(20); z0.add_operator(1.0, "Z 0")
+    K = 2 * c.n_theta + 1
+    e, m = c.psr_full(theta, d_in, n_sel=1, obs_list=[z0], n_marg_bits=2)
+    e, m = e.cpu().numpy().reshape(K), m.cpu().numpy().reshape(K, 4)
+    assert np.abs(m.sum(axis=1) - 1).max() < TOL
+    assert np.abs(e - (m[:, 0] - m[:, 1] + m[:, 2] - m[:, 3])).max() < TOL
+    si, sp, sv = cpu_oracle.psr_lists(1, c.n_theta)
+    pick = np.sort(rng.choice(K, 24, replace=False))
+    e2, m2 = c.eval_batch(theta, d_in, si[pick], sp[pick], sv[pick], obs_list=[z0], n_marg_bits=2)
+    assert np.abs(e2.cpu().numpy()[:, 0] - e[pick]).max() < TOL
+    assert np.abs(m2.cpu().numpy() - m[pick]).max() < TOL
+    for i in (5, 300, c.n_theta - 1):
+        h = 1e-5
+        fd, _ = c.eval_batch(theta, d_in, np.zeros(2, np.int32), np.array([i, i], np.int32), np.array([h, -h]), obs_list=[z0])
+        fd = fd.cpu().numpy()[:, 0]
+        assert abs(0.5 * (e[2 * i + 1] - e[2 * i + 2]) - (fd[0] - fd[1]) / (2 * h)) < 1e-8
+
+
 def test_sweep_with_shared_and_scaled_parameters():
     """Parameters that enter several gates, or with a coefficient: the sweep falls back
     to explicit shifts or uses the scaled half-angle, and still matches the oracle."""
