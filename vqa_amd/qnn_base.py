@@ -602,14 +602,7 @@ class myQNN_base:
         n_inst[:, 0] = n[-1]
         n_inst[:, 1::2] = n[:P].T
         n_inst[:, 2::2] = n[:P].T
-        if sampled:
-            from .sampling import sample_z_means
-
-            M = sample_z_means(E, n_inst.to(torch.int64), seed)
-        else:
-            gen = torch.Generator(device=E.device)
-            gen.manual_seed(seed)
-            M = E + torch.randn((B, K), dtype=torch.float64, device=E.device, generator=gen) * torch.sqrt((1.0 - E * E) / n_inst)
+        M = self._device_estimates(E, n_inst, sampled, seed)
         M0 = M[:, 0]
         n0 = n[-1]
         M0sq = (n0 / (n0 - 1.0)) * M0 * M0 - 1.0 / (n0 - 1.0)           # unbiased square, myQNNs_base.py:843
@@ -625,6 +618,134 @@ class myQNN_base:
         out = np.zeros_like(params)
         out[:] = grad.cpu().numpy()
         return out
+
+    def _device_estimates(self, E, n_inst, sampled, seed):
+        """One estimate of every exact value in E [B, K] from n_inst shots each, on E's device:
+        CLT deviates (myQNNs_base.py:895-900) or sampled means (715-738)."""
+        import torch
+
+        if sampled:
+            from .sampling import sample_z_means
+
+            return sample_z_means(E, n_inst.to(torch.int64), seed)
+        gen = torch.Generator(device=E.device)
+        gen.manual_seed(seed)
+        return E + torch.randn(E.shape, dtype=torch.float64, device=E.device, generator=gen) * torch.sqrt((1.0 - E * E) / n_inst)
+
+    def _ieval_on_device(self, params, n_shots_list, wt_dist, eval_ind, y_eval, min_approx, size, Max_n_shots0,
+                         second_order, _estimates=None):
+        """MSE_iEval (myQNNs_base.py:1421-1596, the branches without the -10 debug mode) with every
+        per-sample array kept on the GPU: the estimator polynomials and their batch means, including
+        the alternatives the reference falls back to when a mean comes out negative (1242-1248,
+        1274-1286, 1314-1315), are evaluated for all parameters at once, and only the five vectors
+        of P+1 numbers come back ('grad_data_list' stays a device tensor).  The reference hands the
+        PARTLY filled (P+1, B) matrix of per-sample gradients to its batch-variance estimator
+        (1488, 1578): row sums are accumulated in that order here.  None when the circuit does not
+        compute on a GPU or the batch mixes CLT and sampled estimates."""
+        P = self.n_c_params
+        n_list = np.asarray(n_shots_list, dtype=float)
+        n0 = float(n_list[-1])
+        n_shots0 = float(np.max(n_list)) if Max_n_shots0 else n0
+        nb_h = np.floor(n_shots0 * wt_dist)                                    # [B]
+        ni_h = np.floor(n_list[:P, None] * wt_dist[None, :])                   # [P, B]
+        lo = min(nb_h.min(), ni_h.min()) if P else nb_h.min()
+        hi = max(nb_h.max(), ni_h.max()) if P else nb_h.max()
+        if lo < 4:
+            return None
+        if min_approx >= 0 and lo >= min_approx:
+            sampled = False
+        elif min_approx < 0 or hi < min_approx:
+            sampled = True
+        else:
+            return None
+        E = self._psr_all(params, eval_ind, keep_on_device=True)
+        if not hasattr(E, "detach"):
+            return None
+        import torch
+
+        dev = E.device
+        B, K = int(E.shape[0]), int(E.shape[1])
+        w = float(params[-1])
+        y = torch.from_numpy(np.ascontiguousarray(y_eval, dtype=np.float64)).to(dev)
+        nb = torch.from_numpy(nb_h).to(dev)
+        ni = torch.from_numpy(ni_h).to(dev)
+        n_inst = torch.empty((B, K), dtype=torch.float64, device=dev)
+        n_inst[:, 0] = nb
+        n_inst[:, 1::2] = ni.T
+        n_inst[:, 2::2] = ni.T
+        seed = int(np.random.randint(0, 2 ** 31 - 1))
+        M = self._device_estimates(E, n_inst, sampled, seed) if _estimates is None else _estimates
+        # unshifted circuit: unbiased powers 1..4 (myQNNs_base.py:843-847) and sample variance (902)
+        EX = M[:, 0]
+        n = nb
+        EX_2 = (n / (n - 1.0)) * EX ** 2 - 1.0 / (n - 1.0)
+        EX_3 = (n / (n - 1.0)) * (n / (n - 2.0)) * EX ** 3 - (3.0 * n - 2.0) / (n - 1.0) / (n - 2.0) * EX
+        EX_4 = (n / (n - 1.0)) * (n / (n - 2.0)) * (n / (n - 3.0)) * EX ** 4 \
+            - ((n / (n - 1.0)) * ((6.0 * n - 8.0) / (n - 2.0)) * EX ** 2 - 3.0 / (n - 1.0)) / (n - 3.0)
+        var_0 = n / (n - 1.0) * (1.0 - EX ** 2)
+        a, b = -2.0 * y, 2.0 * w
+        so = bool(second_order and n0)
+        gd_last = 2.0 * (-y * EX + w * EX_2)                                   # [B]
+        # scale parameter: conditional variance, its fallback, and the batch variance
+        est = a ** 2 + 4.0 * a * b * EX + (4.0 * b ** 2 - a ** 2) * EX_2 - 4.0 * a * b * EX_3 - 4.0 * b ** 2 * EX_4
+        if so:
+            est = est + 2.0 * b ** 2 * (1.0 - 2.0 * EX + EX_2) / (n0 - 1.0)
+        ev_last = float(est.mean())
+        if ev_last < 0:
+            est = (a + 2.0 * b * EX) ** 2 * var_0
+            if so:
+                est = est + 2.0 * b ** 2 * var_0 ** 2 / (n0 - 1.0)
+            ev_last = float(est.mean())
+        N_all = float((P + 1) * B)
+
+        def batch_var(sum_gd2, S1, S2):
+            """_estimate_MSEgrad_Var_condMean on sums: S1, S2 = sum and sum of squares of the matrix so far."""
+            v = sum_gd2 / size - (S1 ** 2 - S2) / (size * (size - 1.0))
+            alt = (S2 - S1 ** 2 / N_all) / (N_all - 1.0)                        # np.var(matrix, ddof=1), zero rows included
+            return torch.where(v < 0, alt, v)
+
+        s1_last, s2_last = gd_last.sum(), (gd_last ** 2).sum()
+        gd2_last = (a ** 2 * EX_2 + 2.0 * a * b * EX_3 + b ** 2 * EX_4).sum()
+        b_last = float(batch_var(gd2_last, s1_last, s2_last))
+        grad = np.zeros_like(params, dtype=float)
+        gvar_b, gvar_EV, gvar_EVi, gvar_EV0 = (np.zeros_like(grad) for _ in range(4))
+        grad[-1] = float(gd_last.mean())
+        gvar_EV[-1] = gvar_EV0[-1] = ev_last
+        gvar_b[-1] = b_last
+        gd = torch.empty((P + 1, B), dtype=torch.float64, device=dev)
+        gd[P] = gd_last
+        if P:
+            Mp, Mm = M[:, 1::2].T, M[:, 2::2].T                                # [P, B]
+            EXp_2 = (ni / (ni - 1.0)) * Mp ** 2 - 1.0 / (ni - 1.0)
+            EXm_2 = (ni / (ni - 1.0)) * Mm ** 2 - 1.0 / (ni - 1.0)
+            var_p = ni / (ni - 1.0) * (1.0 - Mp ** 2)
+            var_m = ni / (ni - 1.0) * (1.0 - Mm ** 2)
+            gd[:P] = ((w * EX - y) * w)[None, :] * (Mp - Mm)
+            w2 = w * w
+            err2 = (y ** 2 - 2.0 * w * y * EX + w2 * EX_2)[None, :]
+            dp2 = EXp_2 - 2.0 * Mp * Mm + EXm_2
+            var_dpdt = w2 * (var_p + var_m)
+            var_err = (w2 * var_0)[None, :]
+            extra = var_err * var_dpdt / n0 if so else 0.0
+            EV_i = (err2 * var_dpdt + extra).mean(dim=1)
+            EV_0 = (var_err * w2 * dp2).mean(dim=1)
+            mcv = EV_i + EV_0
+            EV_0 = torch.where(EV_0 < 0, (var_err * w2 * (Mp - Mm) ** 2).mean(dim=1), EV_0)
+            EV_i = torch.where(EV_i < 0, (((y - w * EX) ** 2)[None, :] * var_dpdt + extra).mean(dim=1), EV_i)
+            mcv = torch.where(mcv < 0, EV_i + EV_0, mcv)
+            rs1, rs2 = gd[:P].sum(dim=1), (gd[:P] ** 2).sum(dim=1)
+            S1 = s1_last + torch.cumsum(rs1, 0)
+            S2 = s2_last + torch.cumsum(rs2, 0)
+            gd2 = (err2 * w2 * dp2).sum(dim=1)
+            packed = torch.stack([gd[:P].mean(dim=1), mcv, EV_i, EV_0, batch_var(gd2, S1, S2)]).cpu().numpy()
+            grad[:P], gvar_EV[:P], gvar_EVi[:P], gvar_EV0[:P], gvar_b[:P] = packed
+        self.circuit_counter[0] += B * K
+        self.call_counter[0] += (2 if sampled else 1) * B * K
+        self.shots_counter[0] += int(nb_h.sum() + 2 * ni_h.sum())
+        self.cache_train_pred = (w * EX).cpu().numpy()
+        self.cache_y_train_eval = y_eval
+        return {"grad": grad, "gvar_list_EV": gvar_EV, "gvar_list_EVi": gvar_EVi, "gvar_list_EV0": gvar_EV0,
+                "gvar_list_b": gvar_b, "grad_data_list": gd}
 
     def MSE_loss_eval(self, params, n_shots, mini_batch_size=None, option_min_approx=None, option_weight=None):
         """myQNNs_base.py:1397-1419."""
@@ -645,6 +766,11 @@ class myQNN_base:
         gvar_list_EV0 = np.zeros_like(params)
         min_approx, wt_dist, eval_ind, y_eval = self._batch_setup(mini_batch_size, option_min_approx, option_weight)
         size = mini_batch_size
+        if getattr(self, "device_statistics", False) and min_approx != -10:
+            out = self._ieval_on_device(params, n_shots_list, wt_dist, eval_ind, y_eval, min_approx, size,
+                                        Max_n_shots0, second_order)
+            if out is not None:
+                return out
         grad_data_list = np.zeros((len(params), len(eval_ind)))
         E = self._psr_all(params, eval_ind)
         n0 = n_shots_list[-1]
