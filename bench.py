@@ -211,6 +211,9 @@ def main():
                 "n_qubits": n, "depth": d, "batch_per_gpu": B, "n_params": P,
                 "evals_per_step_per_gpu": evals, "engine": args.engine or "auto",
                 "prefix_reuse": True,
+                # parameters whose rotations lie outside the backward light cone of the measured qubit:
+                # their shifted values equal the unshifted one exactly and are copied, not recomputed
+                "light_cone_dead_parameters": int(circ.dead_parameters([z0], 0).sum()),
             },
             "roofline": roofline(bytes_alg, flops_alg, evals, kern_ms, measured),
         }

@@ -195,6 +195,18 @@ int vqa_psr_full_dev(vqa_circuit* c, int device, void* stream,
                      double* d_out_expect, double* d_out_marginal);
 
 /*
+ * Which parameters cannot change the observables and the marginal of a call: out_dead[i] = 1
+ * when every rotation driven by theta[i] lies outside the backward light cone of the measured
+ * qubits (e.g. the last-layer rotations on qubits the observable does not touch), so that both
+ * shifted values of a parameter-shift sweep equal the unshifted one.  vqa_psr_full[_dev] copies
+ * those rows instead of running the circuit; this call reports the set (host only, no GPU
+ * work).  Returns the number of dead parameters or a negative VQA_E* code.  No counterpart in
+ * the reference, which evaluates every shifted circuit (vqa/QNN/myQNNs_base.py:1381-1394).
+ */
+int vqa_dead_parameters(vqa_circuit* c, const vqa_obs* const* obs, int n_obs,
+                        int n_marg_bits, uint8_t* out_dead);
+
+/*
  * Shot sampling.  For each of E rows draws counts[e, 0..n_outcomes) ~ Multinomial(shots[e],
  * probs[e, :]) (row-major; a row of probs is used as given, its last entry takes what the
  * others leave; negative or NaN entries count as 0).  With probs = the marginal of the

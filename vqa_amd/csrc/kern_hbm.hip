@@ -1499,9 +1499,30 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
         hl.pd.plan = &hplan_of(call, hl.mask);
         hl.pd.g = kHGates;
     }
+    // the sweep plan's parameter lists without the parameters that cannot matter for this call's
+    // observables (those join the ones that drive no gate: their rows are copies of row 0)
+    ConeInfo& cone = *call.cone;
+    {
+        std::lock_guard<std::mutex> lk(call.c->mu);
+        if (!cone.hbm_built) {
+            cone.hbm_unused = plan.unused;
+            for (size_t k = 0; k < plan.ord.size(); ++k) {
+                if (cone.dead[plan.ord[k]]) {
+                    cone.hbm_unused.push_back(plan.ord[k]);
+                } else {
+                    cone.hbm_ord.push_back(plan.ord[k]);
+                    cone.hbm_ord_pass.push_back(plan.ord_pass[k]);
+                    cone.hbm_coef.push_back(plan.ord_coef[k]);
+                }
+            }
+            cone.hbm_built = true;
+        }
+    }
+    const std::vector<int32_t>&ord = cone.hbm_ord, &ord_pass = cone.hbm_ord_pass, &unused = cone.hbm_unused;
+    const std::vector<double>& ord_coef = cone.hbm_coef;
     const int64_t D = (int64_t)1 << n;
     const int P = call.c->n_theta, K = 2 * P + 1;
-    const int m = (int)plan.ord.size(), n_unused = (int)plan.unused.size();
+    const int m = (int)ord.size(), n_unused = (int)unused.size();
     const int n_ops = std::max(call.c->n_ops, 1);
     int64_t Cmax;
     int nb;
@@ -1543,11 +1564,11 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
         if (rc) return rc;
     }
     if (m > 0) {
-        VQA_HIP(hipMemcpyAsync(d_ord, plan.ord.data(), (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, call.stream));
-        VQA_HIP(hipMemcpyAsync(d_coef, plan.ord_coef.data(), (size_t)m * sizeof(double), hipMemcpyHostToDevice, call.stream));
+        VQA_HIP(hipMemcpyAsync(d_ord, ord.data(), (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, call.stream));
+        VQA_HIP(hipMemcpyAsync(d_coef, ord_coef.data(), (size_t)m * sizeof(double), hipMemcpyHostToDevice, call.stream));
     }
     if (n_unused > 0)
-        VQA_HIP(hipMemcpyAsync(d_unused, plan.unused.data(), (size_t)n_unused * sizeof(int32_t), hipMemcpyHostToDevice, call.stream));
+        VQA_HIP(hipMemcpyAsync(d_unused, unused.data(), (size_t)n_unused * sizeof(int32_t), hipMemcpyHostToDevice, call.stream));
     const size_t n_pass = plan.passes.size();
     double2* F = st;
     double2* R = st + D;
@@ -1590,7 +1611,7 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
         size_t rpass = 0;
         for (int a = 0; a < m; a += C) {
             const int cnt = std::min(C, m - a);
-            const size_t k0 = (size_t)plan.ord_pass[a], k1 = (size_t)plan.ord_pass[a + cnt - 1];
+            const size_t k0 = (size_t)ord_pass[a], k1 = (size_t)ord_pass[a + cnt - 1];
             const int64_t na = (int64_t)(cnt + 2) * h.n_ops;
             hipLaunchKernelGGL(k_sweep_angles, dim3((unsigned)((na + kT - 1) / kT)), dim3(kT), 0, call.stream, h, j,
                                d_ord + a, cnt + 2, tab);
@@ -1599,7 +1620,7 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
             int live = 0;
             for (size_t k = k0; k < n_pass; ++k) {
                 int fresh = 0;
-                while (live + fresh < cnt && (size_t)plan.ord_pass[a + live + fresh] == k) ++fresh;
+                while (live + fresh < cnt && (size_t)ord_pass[a + live + fresh] == k) ++fresh;
                 if (fresh > 0)
                     hipLaunchKernelGGL(k_spawn, dim3(gD), dim3(kT), 0, call.stream, S + (int64_t)live * D, R, D, fresh);
                 live += fresh;

@@ -80,6 +80,8 @@ struct RegArgs {
     double2* ckpt;     // sweep: per-workgroup checkpoint area
     unsigned* next;    // sweep: work counter (zero at launch); workgroups take samples from it
     RunRec* recs;      // sweep: per-workgroup run records
+    const int32_t* live;  // sweep: the runs to execute, ascending (the others' outputs are filled in by the caller)
+    int n_live;
 #ifdef VQA_PROF
     int ablate;
 #endif
@@ -1118,7 +1120,9 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : VQA_WAVES) void k_reg_psr
         // run -1 is the unshifted circuit; thread 0 keeps what the current patch replaced
         int old_m = -1, old_b = -1, old_a = -1;
         double2 nx = make_double2(0, 0);
-        for (int r = -1; r <= NR; ++r) {
+        const int NL = a.n_live;
+        for (int ri = -1; ri <= NL; ++ri) {
+            const int r = ri < 0 ? -1 : ri < NL ? a.live[ri] : NR;
             VQA_STAMP0
             __syncthreads();   // the previous run is over (tables free); its successor's record is in pz
             int id_m = -1, id_b = -1, id_a = -1, mode = 0, kout = 0, rdiag = -1, rpc = 0;
@@ -1155,7 +1159,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : VQA_WAVES) void k_reg_psr
             __syncthreads();
             VQA_STAMP(1)
             // the next run's record travels while this run computes
-            if (r + 1 < NR && (tid & 63) < 8) nx = recs[(size_t)(r + 1) * 8 + (tid & 63)];
+            if (ri + 1 < NL && (tid & 63) < 8) nx = recs[(size_t)a.live[ri + 1] * 8 + (tid & 63)];
 
             double2 amp[kRegAmps];
             int pc0 = 0;
@@ -1182,7 +1186,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : VQA_WAVES) void k_reg_psr
             }
             VQA_STAMP(3)
             // hand the fetched record over (read by everybody after the barrier on top)
-            if (tid < 8 && r + 1 < NR) pz[tid] = nx;
+            if (tid < 8 && ri + 1 < NL) pz[tid] = nx;
         }
     }
 }
@@ -1213,6 +1217,8 @@ static RegArgs make_args(const EvalCall& call, const void* d_prog) {
     a.ckpt = nullptr;
     a.next = nullptr;
     a.recs = nullptr;
+    a.live = nullptr;
+    a.n_live = 0;
 #ifdef VQA_PROF
     const char* abl = getenv("VQA_ABLATE");
     a.ablate = abl ? atoi(abl) : 0;
@@ -1267,13 +1273,36 @@ int reg_engine_sweep(const EvalCall& call, const void* d_prog, const RegProgram&
     const int grid = (int)std::min<int64_t>(n_samples, (int64_t)256 * per_cu);
     const size_t ck_bytes = (size_t)grid * (P.hdr.n_ddesc + 1) * ((size_t)16 << P.hdr.n);
     const size_t rec_bytes = (size_t)grid * std::max(P.hdr.n_runs, 1) * sizeof(RunRec);
+    // the runs of the parameters that can matter for this call's observables; the rows of the
+    // others are copies of the unshifted row (filled in below)
+    ConeInfo& cone = *call.cone;
+    {
+        std::lock_guard<std::mutex> lk(call.c->mu);
+        if (!cone.reg_built) {
+            for (int r = 0; r < P.hdr.n_runs; ++r)
+                if (!cone.dead[P.runs[r].param]) cone.reg_live_runs.push_back(r);
+            cone.reg_built = true;
+        }
+    }
+    const size_t n_live = cone.reg_live_runs.size();
+    const size_t live_bytes = ((n_live + (size_t)cone.n_dead) * sizeof(int32_t) + 255) & ~(size_t)255;
     void* ws = nullptr;
-    rc = workspace_get(call.device, 256 + ck_bytes + rec_bytes, &ws);
+    rc = workspace_get(call.device, 256 + live_bytes + ck_bytes + rec_bytes, &ws);
     if (rc) return rc;
     a.next = (unsigned*)ws;
-    a.ckpt = (double2*)((char*)ws + 256);
-    a.recs = (RunRec*)((char*)ws + 256 + ck_bytes);
+    int32_t* d_live = (int32_t*)((char*)ws + 256);
+    int32_t* d_dead = d_live + n_live;
+    a.ckpt = (double2*)((char*)ws + 256 + live_bytes);
+    a.recs = (RunRec*)((char*)ws + 256 + live_bytes + ck_bytes);
+    a.live = d_live;
+    a.n_live = (int)n_live;
     VQA_HIP(hipMemsetAsync(a.next, 0, 256, call.stream));
+    // (the lists live as long as the circuit: the asynchronous copies may read them after this returns)
+    if (n_live)
+        VQA_HIP(hipMemcpyAsync(d_live, cone.reg_live_runs.data(), n_live * sizeof(int32_t), hipMemcpyHostToDevice, call.stream));
+    if (cone.n_dead)
+        VQA_HIP(hipMemcpyAsync(d_dead, cone.dead_list.data(), (size_t)cone.n_dead * sizeof(int32_t), hipMemcpyHostToDevice,
+                               call.stream));
     const void* fn = P.hdr.block == 64 ? (const void*)k_reg_psr<64>
                    : P.hdr.block == 128 ? (const void*)k_reg_psr<128>
                    : P.hdr.block == 256 ? (const void*)k_reg_psr<256>
@@ -1286,6 +1315,14 @@ int reg_engine_sweep(const EvalCall& call, const void* d_prog, const RegProgram&
     default: hipLaunchKernelGGL(k_reg_psr<512>, dim3(grid), dim3(512), P.lds_bytes_psr, call.stream, a); break;
     }
     VQA_HIP(hipGetLastError());
+    if (cone.n_dead) {
+        const int K = 2 * call.c->n_theta + 1;
+        rc = fill_dead_rows(call.stream, call.d_out_expect, n_samples, K, call.obs.n_obs, d_dead, cone.n_dead);
+        if (rc) return rc;
+        if (call.n_marg_bits > 0)
+            rc = fill_dead_rows(call.stream, call.d_out_marginal, n_samples, K, 1 << call.n_marg_bits, d_dead, cone.n_dead);
+        if (rc) return rc;
+    }
     return VQA_OK;
 }
 

@@ -138,7 +138,31 @@ __global__ __launch_bounds__(kT) void k_sample_counts(const double* probs, int M
     c[M - 1] = left;
 }
 
+// out[(j * K + 2 i + 1 | 2) * stride + col] = out[(j * K) * stride + col] for the listed parameters i
+__global__ __launch_bounds__(kT) void k_fill_dead(double* out, int64_t n_samples, int K, int stride, const int32_t* list,
+                                                  int n_list) {
+    const int64_t idx = (int64_t)blockIdx.x * kT + threadIdx.x;
+    const int64_t per = (int64_t)n_list * stride;
+    if (idx >= n_samples * per) return;
+    const int64_t j = idx / per;
+    const int r = (int)(idx - j * per), u = r / stride, col = r - u * stride;
+    const double v = out[(j * K) * stride + col];
+    const int64_t rp = j * K + 2 * (int64_t)list[u] + 1;
+    out[rp * stride + col] = v;
+    out[(rp + 1) * stride + col] = v;
+}
+
 }  // namespace
+
+int fill_dead_rows(hipStream_t stream, double* d_out, int64_t n_samples, int K, int stride, const int32_t* d_list,
+                   int n_list) {
+    const int64_t tot = n_samples * n_list * stride;
+    if (tot <= 0 || !d_out) return VQA_OK;
+    hipLaunchKernelGGL(k_fill_dead, dim3((unsigned)((tot + kT - 1) / kT)), dim3(kT), 0, stream, d_out, n_samples, K, stride,
+                       d_list, n_list);
+    VQA_HIP(hipGetLastError());
+    return VQA_OK;
+}
 
 int sample_counts_launch(hipStream_t stream, const double* d_probs, int M, const int64_t* d_shots, int64_t E,
                          uint64_t seed, uint64_t stream_id, int64_t* d_counts) {

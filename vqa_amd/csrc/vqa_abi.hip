@@ -4,6 +4,7 @@
 // entry point replaces: include/vqa_hip.h.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -116,6 +117,65 @@ static int pack_obs(const vqa_circuit* c, const vqa_obs* const* obs, int n_obs, 
     p->off[n_obs] = nt;
     p->n_terms = nt;
     return VQA_OK;
+}
+
+// Backward light cone of the measured qubits through the gate list.  `full`: qubits that carry a
+// general operator of the back-propagated observable, `zonly`: qubits that carry I or Z only.
+// Going backwards, a diagonal gate commutes with Z-type factors; a non-diagonal 1-qubit gate
+// turns a Z-type qubit into a general one; CZ / CNOT hand Z-type (CNOT from its control: general)
+// factors to their partner.  A rotation is live when its qubit carries something it does not
+// commute with; a parameter is dead when none of its rotations is live.
+static std::vector<uint8_t> dead_parameters(const vqa_circuit& c, uint64_t zsupp, uint64_t xsupp) {
+    uint64_t full = xsupp, zonly = zsupp & ~xsupp;
+    std::vector<uint8_t> dead((size_t)c.n_theta, 1);
+    for (int g = c.n_ops - 1; g >= 0; --g) {
+        const vqa_op& op = c.ops[g];
+        const uint64_t b0 = (uint64_t)1 << op.q0, b1 = op.q1 >= 0 ? (uint64_t)1 << op.q1 : 0;
+        bool live = false;
+        switch (op.kind) {
+        case VQA_GATE_H: case VQA_GATE_RX: case VQA_GATE_RY:
+            live = ((full | zonly) & b0) != 0;
+            if (live) { full |= b0; zonly &= ~b0; }
+            break;
+        case VQA_GATE_Z: case VQA_GATE_RZ:
+            live = (full & b0) != 0;
+            break;
+        case VQA_GATE_X: case VQA_GATE_Y:   // Paulis map Z to -Z: types unchanged
+            break;
+        case VQA_GATE_CZ: {
+            const uint64_t f = full;
+            if ((f & b0) && !(f & b1)) zonly |= b1;
+            if ((f & b1) && !(f & b0)) zonly |= b0;
+            break;
+        }
+        case VQA_GATE_CNOT: {   // q0 = target, q1 = control
+            const uint64_t f = full, z = zonly;
+            if (((f | z) & b0) && !(f & b1)) zonly |= b1;          // Z_t -> Z_c Z_t
+            if (f & b1) { full |= b0; zonly &= ~b0; }              // X_c -> X_c X_t
+            break;
+        }
+        default: break;
+        }
+        if (live && op.kind >= VQA_GATE_RX && op.kind <= VQA_GATE_RZ && op.src == VQA_SRC_THETA) dead[op.idx] = 0;
+    }
+    return dead;
+}
+
+static ConeInfo* cone_of(vqa_circuit* c, const ObsPack& obs, int n_marg_bits) {
+    uint64_t zs = n_marg_bits > 0 ? (((uint64_t)1 << n_marg_bits) - 1) : 0, xs = 0;
+    for (int t = 0; t < obs.n_terms; ++t) { zs |= obs.z[t]; xs |= obs.x[t]; }
+    std::lock_guard<std::mutex> lk(c->mu);
+    auto key = std::make_pair(zs & ~xs, xs);
+    auto it = c->cones.find(key);
+    if (it == c->cones.end()) {
+        auto ci = std::make_shared<ConeInfo>();
+        ci->dead = getenv("VQA_NO_CONE") ? std::vector<uint8_t>((size_t)c->n_theta, 0) : dead_parameters(*c, zs, xs);
+        for (int i = 0; i < c->n_theta; ++i)
+            if (ci->dead[i]) ci->dead_list.push_back(i);
+        ci->n_dead = (int)ci->dead_list.size();
+        it = c->cones.emplace(key, ci).first;
+    }
+    return it->second.get();
 }
 
 static int resolve_engine(const vqa_circuit* c) { return c->engine; }
@@ -332,6 +392,7 @@ static int eval_dev_common(vqa_circuit* c, int device, void* stream, const doubl
     call.E = E;
     call.n_marg_bits = n_marg_bits;
     call.n_sweep = spec.psr ? (int)(E / (2 * (int64_t)c->n_theta + 1)) : 0;
+    call.cone = spec.psr ? cone_of(c, call.obs, n_marg_bits) : nullptr;
     call.d_out_expect = d_out_e;
     call.d_out_marginal = d_out_m;
     return run_call(call, ctx);
@@ -441,6 +502,19 @@ int vqa_psr_full(vqa_circuit* c, int device, const double* theta, const double* 
     return VQA_OK;
 }
 
+int vqa_dead_parameters(vqa_circuit* c, const vqa_obs* const* obs, int n_obs, int n_marg_bits, uint8_t* out_dead) {
+    if (!c) VQA_FAIL(VQA_EINVAL, "circuit handle is NULL");
+    if (!out_dead && c->n_theta > 0) VQA_FAIL(VQA_EINVAL, "out_dead is NULL");
+    if (n_marg_bits < 0 || n_marg_bits > c->n_qubits)
+        VQA_FAIL(VQA_EINVAL, "n_marg_bits must be in [0, n_qubits] (got %d)", n_marg_bits);
+    ObsPack pack;
+    int rc = pack_obs(c, obs, n_obs, &pack);
+    if (rc) return rc;
+    const ConeInfo* ci = cone_of(c, pack, n_marg_bits);
+    for (int i = 0; i < c->n_theta; ++i) out_dead[i] = ci->dead[i];
+    return ci->n_dead;
+}
+
 int vqa_sample_counts_dev(int device, void* stream, const double* d_probs, int n_outcomes,
                           const int64_t* d_shots, int64_t E, uint64_t seed, uint64_t stream_id,
                           int64_t* d_counts) {
@@ -512,6 +586,7 @@ int vqa_statevector(vqa_circuit* c, int device, const double* theta, const doubl
     memset(&call.obs, 0, sizeof(call.obs));
     call.n_marg_bits = 0;
     call.n_sweep = 0;
+    call.cone = nullptr;
     call.d_out_expect = nullptr;
     call.d_out_marginal = nullptr;
     rc = hbm_engine_statevector(call, (double*)dst.p);

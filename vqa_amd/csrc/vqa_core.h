@@ -117,6 +117,23 @@ struct vqa_obs {
 
 #include "reg_program.h"
 
+namespace vqa {
+// Which parameters cannot change the measured quantities of a call (their rotations lie outside
+// the backward light cone of the observables' qubits): both shifted values equal the unshifted
+// one, so a parameter-shift sweep copies it instead of running the circuit.  Per (circuit,
+// measured qubits), with the engines' derived lists (built on first use, under the circuit's mutex).
+struct ConeInfo {
+    std::vector<uint8_t> dead;               // [n_theta]
+    int n_dead = 0;
+    std::vector<int32_t> dead_list;          // the dead parameters, ascending
+    bool reg_built = false;
+    std::vector<int32_t> reg_live_runs;      // engine 2: runs of the live parameters, in run order
+    bool hbm_built = false;
+    std::vector<int32_t> hbm_ord, hbm_ord_pass, hbm_unused;   // engine 3: the sweep plan's lists without the dead
+    std::vector<double> hbm_coef;
+};
+}  // namespace vqa
+
 struct vqa_circuit {
     int n_qubits, n_ops, n_theta, n_input;
     int engine;  // resolved engine: 1 LDS, 2 register-blocked, 3 HBM
@@ -124,6 +141,7 @@ struct vqa_circuit {
     std::shared_ptr<vqa::RegProgram> reg;  // host copy of the engine-2 program (may be null)
     std::shared_ptr<void> hbm_plan;        // engine 3: the gate list cut into tiled passes (built on first use)
     std::map<uint64_t, std::shared_ptr<void>> hbm_hplans;   // engine 3: Hadamard layers used to measure X-type terms, by qubit mask
+    std::map<std::pair<uint64_t, uint64_t>, std::shared_ptr<vqa::ConeInfo>> cones;   // by (Z-type, general) measured qubits
     std::mutex mu;
     std::map<int, vqa::DeviceCtx> dev;
 };
@@ -142,6 +160,7 @@ struct EvalCall {  // one batched evaluation, all pointers on the device
     ObsPack obs;
     int n_marg_bits;
     int n_sweep;  // > 0: the instance list is a full parameter-shift sweep over this many samples
+    ConeInfo* cone;  // sweeps: the parameters that cannot matter (never null for a sweep)
     double* d_out_expect;
     double* d_out_marginal;
 };
@@ -156,6 +175,9 @@ int hbm_engine_run(const EvalCall& call);
 bool hbm_engine_can_sweep(const EvalCall& call);
 int hbm_engine_sweep(const EvalCall& call, int n_samples);
 int hbm_engine_statevector(const EvalCall& call, double* d_out_state);
+
+// rows 2i+1, 2i+2 of every sample <- its row 0, for the parameters i of d_list (kern_sample.hip)
+int fill_dead_rows(hipStream_t stream, double* d_out, int64_t n_samples, int K, int stride, const int32_t* d_list, int n_list);
 
 // multinomial outcome counts per row, chain of binomials (kern_sample.hip)
 int sample_counts_launch(hipStream_t stream, const double* d_probs, int M, const int64_t* d_shots, int64_t E,

@@ -187,6 +187,14 @@ class LearningCircuit(GateList):
                                         p(oe) if n_obs else None, p(om)))
         return oe, om
 
+    def dead_parameters(self, obs_list: Sequence[Observable] = (), n_marg_bits: int = 0) -> np.ndarray:
+        """Mask of the parameters whose rotations lie outside the backward light cone of the
+        measured qubits: a sweep returns the unshifted values for them without running the circuit."""
+        out = np.zeros(max(self.n_theta, 1), np.uint8)
+        _lib.check(_lib.lib().vqa_dead_parameters(self.handle(), self._obs_array(obs_list), len(obs_list), n_marg_bits,
+                                                  _lib.nptr(out)))
+        return out[:self.n_theta].astype(bool)
+
     def psr_full(self, theta, inputs, sel=None, n_sel: Optional[int] = None,
                  shift: float = 0.5 * np.pi, obs_list: Sequence[Observable] = (), n_marg_bits: int = 0,
                  stream=None, out_expect=None, out_marginal=None):
