@@ -684,15 +684,19 @@ static bool group_sweeps(TilePlan::Pass& pass, const std::vector<TileGate>& in_o
            pass.dg_total <= kMaxDiagGates;
 }
 
-static TilePlan plan_tiles(int n, const std::vector<vqa_op>& ops) {
+// gate_dead (may be null): gates to leave out (outside the light cone of what a call measures)
+static TilePlan plan_tiles(int n, const std::vector<vqa_op>& ops, const std::vector<uint8_t>* gate_dead = nullptr) {
     TilePlan plan;
+    auto is_dead = [&](size_t g) { return gate_dead && (*gate_dead)[g]; };
     // the gate list with CNOT(c,t) RZ_t CNOT(c,t) sandwiches as ZZ phase gates
     struct PG { int kind, q0, q1, g; };
     std::vector<PG> pg;
     for (size_t i = 0; i < ops.size(); ++i) {
         const vqa_op& op = ops[i];
+        if (is_dead(i)) continue;
         if (op.kind == VQA_GATE_CNOT && i + 2 < ops.size() && ops[i + 1].kind == VQA_GATE_RZ && ops[i + 1].q0 == op.q0 &&
-            ops[i + 2].kind == VQA_GATE_CNOT && ops[i + 2].q0 == op.q0 && ops[i + 2].q1 == op.q1) {
+            ops[i + 2].kind == VQA_GATE_CNOT && ops[i + 2].q0 == op.q0 && ops[i + 2].q1 == op.q1 &&
+            !is_dead(i + 1) && !is_dead(i + 2)) {
             pg.push_back(PG{ kGateZZ, op.q0, op.q1, (int)i + 1 });
             i += 2;
         } else {
@@ -761,10 +765,12 @@ static TilePlan plan_tiles(int n, const std::vector<vqa_op>& ops) {
 // Which parameters a sweep can serve with ONE extra state each: those that drive exactly
 // one rotation (with a non-zero coefficient).  A circuit with a parameter in several
 // gates is left to the explicit instance list.
-static void plan_sweep(TilePlan& plan, int n_theta, const std::vector<vqa_op>& ops) {
+static void plan_sweep(TilePlan& plan, int n_theta, const std::vector<vqa_op>& ops,
+                       const std::vector<uint8_t>* gate_dead = nullptr) {
     std::vector<int> count(n_theta, 0), gate(n_theta, -1);
     for (size_t g = 0; g < ops.size(); ++g) {
         const vqa_op& op = ops[g];
+        if (gate_dead && (*gate_dead)[g]) continue;
         if (op.kind >= VQA_GATE_RX && op.kind <= VQA_GATE_RZ && op.src == VQA_SRC_THETA) {
             ++count[op.idx];
             gate[op.idx] = (int)g;
@@ -1092,6 +1098,23 @@ const TilePlan& plan_of(const EvalCall& call) {
         call.c->hbm_plan = plan;
     }
     return *static_cast<const TilePlan*>(call.c->hbm_plan.get());
+}
+
+// The plan of the circuit without the gates outside the light cone of what the call measures
+// (parameter-shift sweeps; the circuit's own plan when there is nothing to leave out)
+const TilePlan& cone_plan_of(const EvalCall& call) {
+    ConeInfo& cone = *call.cone;
+    if (cone.n_gate_dead == 0) return plan_of(call);
+    std::lock_guard<std::mutex> lk(call.c->mu);
+    if (!cone.hbm_plan) {
+        auto plan = std::make_shared<TilePlan>(plan_tiles(call.c->n_qubits, call.c->ops, &cone.gate_dead));
+        plan_sweep(*plan, call.c->n_theta, call.c->ops, &cone.gate_dead);
+        if (getenv("VQA_PLAN_DEBUG"))
+            fprintf(stderr, "[vqa] tiled plan without %d gates outside the light cone: %zu passes\n", cone.n_gate_dead,
+                    plan->passes.size());
+        cone.hbm_plan = plan;
+    }
+    return *static_cast<const TilePlan*>(cone.hbm_plan.get());
 }
 
 // The plan of a layer of Hadamards on the qubits of `mask`: it turns X factors of Pauli
@@ -1424,7 +1447,7 @@ int hbm_engine_run(const EvalCall& call) {
     PlanDev pd;
     HLayer hl;
     if (tiled(call)) {
-        pd.plan = &plan_of(call);
+        pd.plan = call.cone ? &cone_plan_of(call) : &plan_of(call);
         pd.g = (size_t)call.c->n_ops;
         hl.mask = hlayer_mask(call);
         if (hl.mask) {
@@ -1479,8 +1502,8 @@ int hbm_engine_run(const EvalCall& call) {
 }
 
 bool hbm_engine_can_sweep(const EvalCall& call) {
-    if (!tiled(call) || !call.spec.psr || call.n_sweep <= 0 || call.c->n_theta == 0) return false;
-    return plan_of(call).sweepable;
+    if (!tiled(call) || !call.spec.psr || call.n_sweep <= 0 || call.c->n_theta == 0 || !call.cone) return false;
+    return cone_plan_of(call).sweepable;
 }
 
 // Full parameter-shift sweeps of n_samples samples (rows j * (2P+1) + k of the outputs).
@@ -1490,7 +1513,7 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
     if (call.n_marg_bits > 10)
         VQA_FAIL(VQA_EUNSUPPORTED, "HBM engine: n_marg_bits <= 10 (got %d)", call.n_marg_bits);
     PlanDev pd;
-    pd.plan = &plan_of(call);
+    pd.plan = &cone_plan_of(call);
     pd.g = (size_t)call.c->n_ops;
     const TilePlan& plan = *pd.plan;
     HLayer hl;

@@ -125,9 +125,11 @@ static int pack_obs(const vqa_circuit* c, const vqa_obs* const* obs, int n_obs, 
 // turns a Z-type qubit into a general one; CZ / CNOT hand Z-type (CNOT from its control: general)
 // factors to their partner.  A rotation is live when its qubit carries something it does not
 // commute with; a parameter is dead when none of its rotations is live.
-static std::vector<uint8_t> dead_parameters(const vqa_circuit& c, uint64_t zsupp, uint64_t xsupp) {
+static std::vector<uint8_t> dead_parameters(const vqa_circuit& c, uint64_t zsupp, uint64_t xsupp,
+                                            std::vector<uint8_t>* gate_dead) {
     uint64_t full = xsupp, zonly = zsupp & ~xsupp;
     std::vector<uint8_t> dead((size_t)c.n_theta, 1);
+    gate_dead->assign((size_t)c.n_ops, 0);
     for (int g = c.n_ops - 1; g >= 0; --g) {
         const vqa_op& op = c.ops[g];
         const uint64_t b0 = (uint64_t)1 << op.q0, b1 = op.q1 >= 0 ? (uint64_t)1 << op.q1 : 0;
@@ -141,21 +143,25 @@ static std::vector<uint8_t> dead_parameters(const vqa_circuit& c, uint64_t zsupp
             live = (full & b0) != 0;
             break;
         case VQA_GATE_X: case VQA_GATE_Y:   // Paulis map Z to -Z: types unchanged
+            live = ((full | zonly) & b0) != 0;
             break;
         case VQA_GATE_CZ: {
             const uint64_t f = full;
+            live = (f & (b0 | b1)) != 0;
             if ((f & b0) && !(f & b1)) zonly |= b1;
             if ((f & b1) && !(f & b0)) zonly |= b0;
             break;
         }
         case VQA_GATE_CNOT: {   // q0 = target, q1 = control
             const uint64_t f = full, z = zonly;
+            live = ((f | z) & b0) != 0 || (f & b1) != 0;
             if (((f | z) & b0) && !(f & b1)) zonly |= b1;          // Z_t -> Z_c Z_t
             if (f & b1) { full |= b0; zonly &= ~b0; }              // X_c -> X_c X_t
             break;
         }
         default: break;
         }
+        (*gate_dead)[g] = live ? 0 : 1;
         if (live && op.kind >= VQA_GATE_RX && op.kind <= VQA_GATE_RZ && op.src == VQA_SRC_THETA) dead[op.idx] = 0;
     }
     return dead;
@@ -169,7 +175,12 @@ static ConeInfo* cone_of(vqa_circuit* c, const ObsPack& obs, int n_marg_bits) {
     auto it = c->cones.find(key);
     if (it == c->cones.end()) {
         auto ci = std::make_shared<ConeInfo>();
-        ci->dead = getenv("VQA_NO_CONE") ? std::vector<uint8_t>((size_t)c->n_theta, 0) : dead_parameters(*c, zs, xs);
+        ci->dead = dead_parameters(*c, zs, xs, &ci->gate_dead);
+        if (getenv("VQA_NO_CONE")) {
+            ci->dead.assign((size_t)c->n_theta, 0);
+            ci->gate_dead.assign((size_t)c->n_ops, 0);
+        }
+        for (uint8_t d : ci->gate_dead) ci->n_gate_dead += d;
         for (int i = 0; i < c->n_theta; ++i)
             if (ci->dead[i]) ci->dead_list.push_back(i);
         ci->n_dead = (int)ci->dead_list.size();
@@ -179,6 +190,39 @@ static ConeInfo* cone_of(vqa_circuit* c, const ObsPack& obs, int n_marg_bits) {
 }
 
 static int resolve_engine(const vqa_circuit* c) { return c->engine; }
+
+// Engine 2 runs the circuit WITHOUT the gates outside the call's light cone: the program of
+// that pruned gate list (compiled on first use; the circuit's own program when it has nothing to
+// prune or the pruned list does not compile for sweeps) and its copy on the call's device.
+static int cone_reg_program(const EvalCall& call, const RegProgram** prog, void** d_prog) {
+    ConeInfo& cone = *call.cone;
+    std::lock_guard<std::mutex> lk(call.c->mu);
+    if (!cone.reg_tried) {
+        cone.reg_tried = true;
+        if (cone.n_gate_dead > 0) {
+            std::vector<vqa_op> live;
+            for (int g = 0; g < call.c->n_ops; ++g)
+                if (!cone.gate_dead[g]) live.push_back(call.c->ops[g]);
+            auto rp = std::make_shared<RegProgram>();
+            std::string why;
+            if (reg_compile(call.c->n_qubits, call.c->n_theta, live, rp.get(), &why) &&
+                reg_engine_can_sweep(*rp) == reg_engine_can_sweep(*call.c->reg))
+                cone.reg = rp;
+        }
+    }
+    if (!cone.reg) return VQA_OK;
+    auto it = cone.reg_dev.find(call.device);
+    if (it == cone.reg_dev.end()) {
+        void* d = nullptr;
+        hipError_t e = hipMalloc(&d, cone.reg->blob.size());
+        if (e != hipSuccess) VQA_FAIL(VQA_ENOMEM, "hipMalloc of the compiled program failed: %s", hipGetErrorString(e));
+        VQA_HIP(hipMemcpy(d, cone.reg->blob.data(), cone.reg->blob.size(), hipMemcpyHostToDevice));
+        it = cone.reg_dev.emplace(call.device, d).first;
+    }
+    *prog = cone.reg.get();
+    *d_prog = it->second;
+    return VQA_OK;
+}
 
 static int run_call(EvalCall& call, DeviceCtx* ctx) {
     VQA_HIP(hipSetDevice(call.device));
@@ -193,9 +237,20 @@ static int run_call(EvalCall& call, DeviceCtx* ctx) {
     switch (engine) {
     case 1: return lds_engine_run(call);
     case 2:
-        if (call.spec.psr && call.n_sweep > 0 && reg_engine_can_sweep(*call.c->reg))
-            return reg_engine_sweep(call, ctx->reg_prog, *call.c->reg, call.n_sweep);
-        return reg_engine_run(call, ctx->reg_prog, *call.c->reg);
+        if (call.spec.psr && call.n_sweep > 0 && reg_engine_can_sweep(*call.c->reg)) {
+            const RegProgram* prog = call.c->reg.get();
+            void* d_prog = ctx->reg_prog;
+            int rc = cone_reg_program(call, &prog, &d_prog);
+            if (rc) return rc;
+            if (reg_engine_can_sweep(*prog)) return reg_engine_sweep(call, d_prog, *prog, call.n_sweep);
+        }
+        {
+            const RegProgram* prog = call.c->reg.get();
+            void* d_prog = ctx->reg_prog;
+            int rc = cone_reg_program(call, &prog, &d_prog);
+            if (rc) return rc;
+            return reg_engine_run(call, d_prog, *prog);
+        }
     case 3:
         if (hbm_engine_can_sweep(call)) return hbm_engine_sweep(call, call.n_sweep);
         return hbm_engine_run(call);
@@ -327,6 +382,11 @@ int vqa_circuit_destroy(vqa_circuit* c) {
         if (kv.second.d_ops) (void)hipFree(kv.second.d_ops);
         if (kv.second.reg_prog) (void)hipFree(kv.second.reg_prog);
     }
+    for (auto& kv : c->cones)
+        for (auto& dv : kv.second->reg_dev) {
+            (void)hipSetDevice(dv.first);
+            (void)hipFree(dv.second);
+        }
     delete c;
     return VQA_OK;
 }
@@ -392,7 +452,7 @@ static int eval_dev_common(vqa_circuit* c, int device, void* stream, const doubl
     call.E = E;
     call.n_marg_bits = n_marg_bits;
     call.n_sweep = spec.psr ? (int)(E / (2 * (int64_t)c->n_theta + 1)) : 0;
-    call.cone = spec.psr ? cone_of(c, call.obs, n_marg_bits) : nullptr;
+    call.cone = cone_of(c, call.obs, n_marg_bits);
     call.d_out_expect = d_out_e;
     call.d_out_marginal = d_out_m;
     return run_call(call, ctx);

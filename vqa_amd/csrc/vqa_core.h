@@ -124,7 +124,13 @@ namespace vqa {
 // measured qubits), with the engines' derived lists (built on first use, under the circuit's mutex).
 struct ConeInfo {
     std::vector<uint8_t> dead;               // [n_theta]
-    int n_dead = 0;
+    std::vector<uint8_t> gate_dead;          // [n_ops]: gates outside the cone (they cannot change the measured values either)
+    int n_dead = 0, n_gate_dead = 0;
+    // the circuit without its dead gates, compiled for the sweeps of this cone
+    bool reg_tried = false;
+    std::shared_ptr<RegProgram> reg;         // engine 2 (null: use the circuit's own program)
+    std::map<int, void*> reg_dev;            // its device copies
+    std::shared_ptr<void> hbm_plan;          // engine 3
     std::vector<int32_t> dead_list;          // the dead parameters, ascending
     bool reg_built = false;
     std::vector<int32_t> reg_live_runs;      // engine 2: runs of the live parameters, in run order
@@ -160,7 +166,7 @@ struct EvalCall {  // one batched evaluation, all pointers on the device
     ObsPack obs;
     int n_marg_bits;
     int n_sweep;  // > 0: the instance list is a full parameter-shift sweep over this many samples
-    ConeInfo* cone;  // sweeps: the parameters that cannot matter (never null for a sweep)
+    ConeInfo* cone;  // what cannot matter for this call's observables (null: the state itself is asked for)
     double* d_out_expect;
     double* d_out_marginal;
 };
