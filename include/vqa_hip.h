@@ -195,6 +195,21 @@ int vqa_psr_full_dev(vqa_circuit* c, int device, void* stream,
                      double* d_out_expect, double* d_out_marginal);
 
 /*
+ * vqa_psr_full_dev for a SUBSET of the parameters: param_mask is a HOST array of P bytes
+ * (NULL = all); only the unshifted row and the rows k = 2i+1, 2i+2 of parameters with
+ * param_mask[i] != 0 are guaranteed to be written, the others may be left untouched.  For
+ * sharding the shifted evaluations of ONE circuit over several GPUs (a VQE energy gradient:
+ * the loop over parameters of the reference's vqe optimizers' targets,
+ * vqa/VQA_optimizers/vqe_optimizers.py:207-242, 637), every rank asking for its own
+ * parameters.  With a mask the call waits for its work on `stream` before it returns.
+ */
+int vqa_psr_params_dev(vqa_circuit* c, int device, void* stream,
+                       const double* d_theta, const double* d_input_angles, int B,
+                       const int32_t* d_sel, int n_sel, double shift, const uint8_t* param_mask,
+                       const vqa_obs* const* obs, int n_obs, int n_marg_bits,
+                       double* d_out_expect, double* d_out_marginal);
+
+/*
  * Which parameters cannot change the observables and the marginal of a call: out_dead[i] = 1
  * when every rotation driven by theta[i] lies outside the backward light cone of the measured
  * qubits (e.g. the last-layer rotations on qubits the observable does not touch), so that both

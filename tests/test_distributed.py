@@ -67,3 +67,42 @@ def test_two_rank_gradient_equals_single_process():
         assert p.exitcode == 0
     for r in range(2):
         assert np.max(np.abs(got[r] - want)) < 1e-13
+
+
+def vqe_problem():
+    from test_vqe_target import make
+    return make(n=5, d=2, min_approx=-10)
+
+
+def vqe_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    v, p = vqe_problem()
+    v.group = dist.group.WORLD
+    out = v.iEval(p, np.full(v.n_params, 100))
+    q.put((rank, out["grad"], out["gvar_list"], v.circuit_counter[0]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_vqe_gradient_shards_the_parameters():
+    """The Pauli-sum target with its shifted evaluations dealt round-robin to two ranks (each sweeps
+    its own parameters, one all-reduce) against the one-process gradient."""
+    v, p = vqe_problem()
+    want = v.iEval(p, np.full(v.n_params, 100))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=vqe_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    got = [q.get(timeout=120) for _ in procs]
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    for rank, grad, gvar, n_circ in got:
+        assert np.max(np.abs(grad - want["grad"])) < 1e-13
+        assert np.max(np.abs(gvar - want["gvar_list"])) < 1e-13
+        assert n_circ == 2 * v.n_params

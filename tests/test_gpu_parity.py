@@ -369,6 +369,29 @@ def test_streaming_sweep_with_pauli_sums(n, d):
     assert np.abs(got_e2 - want_e[:7]).max() < 1e-9
 
 
+@pytest.mark.parametrize("n,d,builder", [(12, 2, create_ibm_HEA_ansatz), (14, 2, create_ry_cz_ansatz)])
+def test_parameter_subset_sweep(n, d, builder):
+    """vqa_psr_params_dev: the rows of the requested parameters (dead ones included) and the
+    unshifted row equal the full sweep's; register engine and streaming engine."""
+    c = builder(n, d, seed=1)
+    rng = np.random.default_rng(n)
+    theta = rng.uniform(-3, 3, c.n_theta)
+    x = rng.uniform(0, np.pi, (2, n))
+    d_in = c.upload_inputs(x)
+    z0 = Observable(n); z0.add_operator(1.0, "Z 0"); z0.add_operator(0.3, "Z 1 Z 2")
+    full_e, full_m = c.psr_full(theta, d_in, obs_list=[z0], n_marg_bits=2)
+    mine = np.arange(1, c.n_theta, 3)
+    e, m = c.psr_full(theta, d_in, obs_list=[z0], n_marg_bits=2, params=mine)
+    rows = np.concatenate([[0], 2 * mine + 1, 2 * mine + 2])
+    assert float((e[:, rows] - full_e[:, rows]).abs().max()) < TOL
+    assert float((m[:, rows] - full_m[:, rows]).abs().max()) < TOL
+    assert c.dead_parameters([z0], 2)[mine].any()          # the subset holds parameters outside the light cone too
+    # host arrays in, host arrays out
+    eh, _ = c.psr_full(theta, c.input_angles(x), obs_list=[z0], params=mine[:2])
+    assert isinstance(eh, np.ndarray)
+    assert np.abs(eh[:, [0, 2 * mine[0] + 1, 2 * mine[1] + 2]] - full_e.cpu().numpy()[:, [0, 2 * mine[0] + 1, 2 * mine[1] + 2]]).max() < TOL
+
+
 def test_tiled_passes_against_gate_sweeps_22_qubits():
     """Beyond what the oracle finishes quickly: the tiled passes of the HBM engine against its
     one-sweep-per-gate form (independent kernels) on a 22-qubit circuit with all gate kinds."""

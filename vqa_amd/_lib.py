@@ -20,7 +20,7 @@ EXPORTS = (
     "vqa_circuit_create", "vqa_circuit_destroy", "vqa_circuit_info",
     "vqa_observable_create", "vqa_observable_destroy",
     "vqa_eval_batch", "vqa_eval_batch_dev", "vqa_psr_full", "vqa_psr_full_dev",
-    "vqa_statevector", "vqa_sample_counts", "vqa_sample_counts_dev", "vqa_dead_parameters",
+    "vqa_statevector", "vqa_sample_counts", "vqa_sample_counts_dev", "vqa_dead_parameters", "vqa_psr_params_dev",
 )
 
 
@@ -63,6 +63,8 @@ def lib():
     L.vqa_psr_full_dev.argtypes = [vp, C.c_int, vp, dp, dp, C.c_int, ip, C.c_int, C.c_double,
                                    vp, C.c_int, C.c_int, dp, dp]
     L.vqa_statevector.argtypes = [vp, C.c_int, dp, dp, C.c_int, C.c_double, dp]
+    L.vqa_psr_params_dev.argtypes = [vp, C.c_int, vp, dp, dp, C.c_int, ip, C.c_int, C.c_double, vp,
+                                     vp, C.c_int, C.c_int, dp, dp]
     L.vqa_dead_parameters.argtypes = [vp, vp, C.c_int, C.c_int, vp]
     L.vqa_sample_counts.argtypes = [C.c_int, dp, C.c_int, ip, C.c_int64, C.c_uint64, C.c_uint64, ip]
     L.vqa_sample_counts_dev.argtypes = [C.c_int, vp, dp, C.c_int, ip, C.c_int64, C.c_uint64, C.c_uint64, ip]

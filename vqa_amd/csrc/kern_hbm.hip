@@ -1541,8 +1541,24 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
             cone.hbm_built = true;
         }
     }
-    const std::vector<int32_t>&ord = cone.hbm_ord, &ord_pass = cone.hbm_ord_pass, &unused = cone.hbm_unused;
-    const std::vector<double>& ord_coef = cone.hbm_coef;
+    // a caller's parameter subset: per-call copies of the lists (the call then waits for the stream
+    // before it returns, so that the asynchronous copies have read them)
+    std::vector<int32_t> m_ord, m_ord_pass, m_unused;
+    std::vector<double> m_coef;
+    if (call.param_mask) {
+        for (size_t k = 0; k < cone.hbm_ord.size(); ++k) {
+            if (!call.param_mask[cone.hbm_ord[k]]) continue;
+            m_ord.push_back(cone.hbm_ord[k]);
+            m_ord_pass.push_back(cone.hbm_ord_pass[k]);
+            m_coef.push_back(cone.hbm_coef[k]);
+        }
+        for (int32_t i : cone.hbm_unused)
+            if (call.param_mask[i]) m_unused.push_back(i);
+    }
+    const std::vector<int32_t>& ord = call.param_mask ? m_ord : cone.hbm_ord;
+    const std::vector<int32_t>& ord_pass = call.param_mask ? m_ord_pass : cone.hbm_ord_pass;
+    const std::vector<int32_t>& unused = call.param_mask ? m_unused : cone.hbm_unused;
+    const std::vector<double>& ord_coef = call.param_mask ? m_coef : cone.hbm_coef;
     const int64_t D = (int64_t)1 << n;
     const int P = call.c->n_theta, K = 2 * P + 1;
     const int m = (int)ord.size(), n_unused = (int)unused.size();
@@ -1661,6 +1677,7 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
         }
     }
     VQA_HIP(hipGetLastError());
+    if (call.param_mask) VQA_HIP(hipStreamSynchronize(call.stream));
     return VQA_OK;
 }
 

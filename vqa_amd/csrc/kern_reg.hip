@@ -1284,8 +1284,20 @@ int reg_engine_sweep(const EvalCall& call, const void* d_prog, const RegProgram&
             cone.reg_built = true;
         }
     }
-    const size_t n_live = cone.reg_live_runs.size();
-    const size_t live_bytes = ((n_live + (size_t)cone.n_dead) * sizeof(int32_t) + 255) & ~(size_t)255;
+    // a caller's parameter subset: per-call copies of the two lists (the call then waits for the
+    // stream before it returns, so that the asynchronous copies have read them)
+    std::vector<int32_t> m_live, m_dead;
+    if (call.param_mask) {
+        for (int32_t r : cone.reg_live_runs)
+            if (call.param_mask[P.runs[r].param]) m_live.push_back(r);
+        for (int32_t i : cone.dead_list)
+            if (call.param_mask[i]) m_dead.push_back(i);
+    }
+    const std::vector<int32_t>& live_runs = call.param_mask ? m_live : cone.reg_live_runs;
+    const std::vector<int32_t>& dead_list = call.param_mask ? m_dead : cone.dead_list;
+    const int n_dead = (int)dead_list.size();
+    const size_t n_live = live_runs.size();
+    const size_t live_bytes = ((n_live + (size_t)n_dead) * sizeof(int32_t) + 255) & ~(size_t)255;
     void* ws = nullptr;
     rc = workspace_get(call.device, 256 + live_bytes + ck_bytes + rec_bytes, &ws);
     if (rc) return rc;
@@ -1299,9 +1311,9 @@ int reg_engine_sweep(const EvalCall& call, const void* d_prog, const RegProgram&
     VQA_HIP(hipMemsetAsync(a.next, 0, 256, call.stream));
     // (the lists live as long as the circuit: the asynchronous copies may read them after this returns)
     if (n_live)
-        VQA_HIP(hipMemcpyAsync(d_live, cone.reg_live_runs.data(), n_live * sizeof(int32_t), hipMemcpyHostToDevice, call.stream));
-    if (cone.n_dead)
-        VQA_HIP(hipMemcpyAsync(d_dead, cone.dead_list.data(), (size_t)cone.n_dead * sizeof(int32_t), hipMemcpyHostToDevice,
+        VQA_HIP(hipMemcpyAsync(d_live, live_runs.data(), n_live * sizeof(int32_t), hipMemcpyHostToDevice, call.stream));
+    if (n_dead)
+        VQA_HIP(hipMemcpyAsync(d_dead, dead_list.data(), (size_t)n_dead * sizeof(int32_t), hipMemcpyHostToDevice,
                                call.stream));
     const void* fn = P.hdr.block == 64 ? (const void*)k_reg_psr<64>
                    : P.hdr.block == 128 ? (const void*)k_reg_psr<128>
@@ -1315,14 +1327,15 @@ int reg_engine_sweep(const EvalCall& call, const void* d_prog, const RegProgram&
     default: hipLaunchKernelGGL(k_reg_psr<512>, dim3(grid), dim3(512), P.lds_bytes_psr, call.stream, a); break;
     }
     VQA_HIP(hipGetLastError());
-    if (cone.n_dead) {
+    if (n_dead) {
         const int K = 2 * call.c->n_theta + 1;
-        rc = fill_dead_rows(call.stream, call.d_out_expect, n_samples, K, call.obs.n_obs, d_dead, cone.n_dead);
+        rc = fill_dead_rows(call.stream, call.d_out_expect, n_samples, K, call.obs.n_obs, d_dead, n_dead);
         if (rc) return rc;
         if (call.n_marg_bits > 0)
-            rc = fill_dead_rows(call.stream, call.d_out_marginal, n_samples, K, 1 << call.n_marg_bits, d_dead, cone.n_dead);
+            rc = fill_dead_rows(call.stream, call.d_out_marginal, n_samples, K, 1 << call.n_marg_bits, d_dead, n_dead);
         if (rc) return rc;
     }
+    if (call.param_mask) VQA_HIP(hipStreamSynchronize(call.stream));
     return VQA_OK;
 }
 

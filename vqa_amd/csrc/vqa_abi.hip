@@ -429,7 +429,7 @@ int vqa_observable_destroy(vqa_obs* o) {
 static int eval_dev_common(vqa_circuit* c, int device, void* stream, const double* d_theta,
                            const double* d_input, int B, const EvalSpec& spec, int64_t E,
                            const vqa_obs* const* obs, int n_obs, int n_marg_bits, double* d_out_e,
-                           double* d_out_m) {
+                           double* d_out_m, const uint8_t* param_mask = nullptr) {
     int rc = check_common(c, device, d_theta, d_input, B, n_obs, n_marg_bits, d_out_e, d_out_m);
     if (rc) return rc;
     if (E < 0) VQA_FAIL(VQA_EINVAL, "E must be >= 0");
@@ -453,6 +453,7 @@ static int eval_dev_common(vqa_circuit* c, int device, void* stream, const doubl
     call.n_marg_bits = n_marg_bits;
     call.n_sweep = spec.psr ? (int)(E / (2 * (int64_t)c->n_theta + 1)) : 0;
     call.cone = cone_of(c, call.obs, n_marg_bits);
+    call.param_mask = param_mask;
     call.d_out_expect = d_out_e;
     call.d_out_marginal = d_out_m;
     return run_call(call, ctx);
@@ -484,6 +485,20 @@ int vqa_psr_full_dev(vqa_circuit* c, int device, void* stream, const double* d_t
     const int64_t E = (int64_t)n_sel * (2 * (int64_t)c->n_theta + 1);
     return eval_dev_common(c, device, stream, d_theta, d_input_angles, B, spec, E, obs, n_obs,
                            n_marg_bits, d_out_expect, d_out_marginal);
+}
+
+int vqa_psr_params_dev(vqa_circuit* c, int device, void* stream, const double* d_theta,
+                       const double* d_input_angles, int B, const int32_t* d_sel, int n_sel,
+                       double shift, const uint8_t* param_mask, const vqa_obs* const* obs, int n_obs,
+                       int n_marg_bits, double* d_out_expect, double* d_out_marginal) {
+    if (!c) VQA_FAIL(VQA_EINVAL, "circuit handle is NULL");
+    if (n_sel < 0) VQA_FAIL(VQA_EINVAL, "n_sel must be >= 0");
+    if (!d_sel && c->n_input > 0 && n_sel > B)
+        VQA_FAIL(VQA_EINVAL, "sel is NULL but n_sel (%d) > B (%d)", n_sel, B);
+    EvalSpec spec = { nullptr, nullptr, nullptr, d_sel, 1, c->n_theta, shift, c->n_input > 0 ? B : 0, c->n_theta };
+    const int64_t E = (int64_t)n_sel * (2 * (int64_t)c->n_theta + 1);
+    return eval_dev_common(c, device, stream, d_theta, d_input_angles, B, spec, E, obs, n_obs,
+                           n_marg_bits, d_out_expect, d_out_marginal, param_mask);
 }
 
 static int check_indices(const vqa_circuit* c, int B, const int32_t* idx, int64_t n, const char* what) {
@@ -647,6 +662,7 @@ int vqa_statevector(vqa_circuit* c, int device, const double* theta, const doubl
     call.n_marg_bits = 0;
     call.n_sweep = 0;
     call.cone = nullptr;
+    call.param_mask = nullptr;
     call.d_out_expect = nullptr;
     call.d_out_marginal = nullptr;
     rc = hbm_engine_statevector(call, (double*)dst.p);

@@ -166,6 +166,7 @@ struct EvalCall {  // one batched evaluation, all pointers on the device
     ObsPack obs;
     int n_marg_bits;
     int n_sweep;  // > 0: the instance list is a full parameter-shift sweep over this many samples
+    const uint8_t* param_mask;  // sweeps: HOST array [n_theta], 0 = this parameter's two rows are not wanted (null: all)
     ConeInfo* cone;  // what cannot matter for this call's observables (null: the state itself is asked for)
     double* d_out_expect;
     double* d_out_marginal;

@@ -197,11 +197,14 @@ class LearningCircuit(GateList):
 
     def psr_full(self, theta, inputs, sel=None, n_sel: Optional[int] = None,
                  shift: float = 0.5 * np.pi, obs_list: Sequence[Observable] = (), n_marg_bits: int = 0,
-                 stream=None, out_expect=None, out_marginal=None):
+                 stream=None, out_expect=None, out_marginal=None, params=None):
         """Full parameter-shift sweep (2P+1 instances per selected sample).
         numpy ``inputs``: host-pointer path, returns numpy; torch cuda tensor:
         device path, asynchronous on the current torch stream, returns tensors
-        shaped ``[n_sel, 2P+1, n_obs]`` and ``[n_sel, 2P+1, 2^m]``."""
+        shaped ``[n_sel, 2P+1, n_obs]`` and ``[n_sel, 2P+1, 2^m]``.
+        ``params``: indices of the parameters whose shifted rows are wanted (the
+        others are zero or computed anyway); for sharding one circuit's shifts
+        over several GPUs."""
         torch = _torch()
         L = _lib.lib()
         n_obs, M, K = len(obs_list), 1 << n_marg_bits, 2 * self.n_theta + 1
@@ -209,6 +212,26 @@ class LearningCircuit(GateList):
         B = 0 if inputs is None else int(inputs.shape[0])
         if n_sel is None:
             n_sel = len(sel) if sel is not None else max(B, 1)
+        if params is not None:
+            host = not isinstance(inputs, torch.Tensor) and not isinstance(theta, torch.Tensor)
+            mask = np.zeros(max(self.n_theta, 1), np.uint8)
+            mask[np.asarray(params, dtype=np.int64)] = 1
+            dev = f"cuda:{self.device}"
+            th = self.to_device(theta, np.float64)
+            ia = None if inputs is None else self.to_device(inputs, np.float64)
+            se = None if sel is None else self.to_device(sel, np.int32)
+            oe = out_expect if out_expect is not None else torch.zeros((n_sel, K, n_obs), dtype=torch.float64, device=dev)
+            om = out_marginal
+            if om is None and n_marg_bits > 0:
+                om = torch.zeros((n_sel, K, M), dtype=torch.float64, device=dev)
+            st = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
+            p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+            _lib.check(L.vqa_psr_params_dev(self.handle(), self.device, C.c_void_p(st), p(th), p(ia), B, p(se), n_sel,
+                                            float(shift), _lib.nptr(mask), oarr, n_obs, n_marg_bits,
+                                            p(oe) if n_obs else None, p(om)))
+            if host:
+                return oe.cpu().numpy(), None if om is None else om.cpu().numpy()
+            return oe, om
         if not isinstance(inputs, torch.Tensor) and not isinstance(theta, torch.Tensor):
             theta = np.ascontiguousarray(theta, np.float64)
             ia = None if inputs is None else np.ascontiguousarray(inputs, np.float64)

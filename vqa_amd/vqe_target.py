@@ -64,6 +64,7 @@ class PauliSumVQE:
         # circuits without input gates take one dummy sample
         self._x = np.zeros((1, 1)) if x is None else np.atleast_2d(np.asarray(x, dtype=float))
         self._inputs = None
+        self.group = None   # a torch.distributed process group: shard the shifted evaluations over its ranks
         self.methods_for_optimization = {}
         self.set_methods_for_optimizer(setting_dict or {
             "func_to_track": "exact_energy", "loss": "energy_eval", "grad": "grad_eval",
@@ -77,6 +78,7 @@ class PauliSumVQE:
         d = dict(self.__dict__)
         d["_inputs"] = None
         d["terms"] = None
+        d["group"] = None
         d["methods_for_optimization"] = {k: v.__name__ for k, v in self.methods_for_optimization.items()}
         return d
 
@@ -132,7 +134,12 @@ class PauliSumVQE:
     def _shifted_term_expectations(self, params):
         """Exact <P_t> at theta_i +- pi/2 for every parameter, [2P, T] (+ first, - second): one full
         parameter-shift sweep on the device (the engines share work between the shifts of a
-        sweep; an explicit instance list would start every shifted circuit from |0>)."""
+        sweep; an explicit instance list would start every shifted circuit from |0>).
+
+        With ``self.group`` set to a torch.distributed process group (one process per GPU) the
+        parameters are dealt round-robin to the ranks: each rank sweeps its own parameters and
+        one all-reduce (sum of matrices that are zero outside a rank's rows) puts the whole
+        [2P, T] matrix on every rank."""
         if not hasattr(self.circuit, "psr_full"):
             sp, sv = self._shift_lists()
             return self._term_expectations(params, sp, sv)
@@ -140,10 +147,29 @@ class PauliSumVQE:
             self._inputs = self.circuit.upload_inputs(self._x)
         theta = np.asarray(params[:self.n_c_params], dtype=np.float64)
         P = self.n_c_params
-        out = np.empty((2 * P, len(self.terms)))
+        rank, world = 0, 1
+        group = getattr(self, "group", None)
+        if group is not None:
+            import torch.distributed as dist
+
+            rank, world = dist.get_rank(group), dist.get_world_size(group)
+        mine = np.arange(rank, P, world)
+        out = np.zeros((2 * P, len(self.terms)))
+        rows = np.concatenate([2 * mine, 2 * mine + 1])
         for lo in range(0, len(self.terms), 64):      # the library takes up to 64 observables per call
-            e, _ = self.circuit.psr_full(theta, self._inputs, n_sel=1, obs_list=self.terms[lo:lo + 64])
-            out[:, lo:lo + 64] = _np(e)[0, 1:, :]
+            e, _ = self.circuit.psr_full(theta, self._inputs, n_sel=1, obs_list=self.terms[lo:lo + 64],
+                                         params=None if world == 1 else mine)
+            out[rows, lo:lo + 64] = _np(e)[0, 1:, :][rows]
+        if world > 1:
+            import torch
+
+            from .distributed import all_reduce_sum
+
+            dev = getattr(self._inputs, "device", "cpu")
+            t = torch.from_numpy(out).to(dev)
+            all_reduce_sum(t, group=group)
+            out = t.cpu().numpy()
+        # counters: every rank accounts for the whole sweep (they describe the job, not the rank)
         self.circuit_counter[0] += 2 * P
         self.call_counter[0] += 2 * P
         return out
