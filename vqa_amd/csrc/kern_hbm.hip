@@ -28,6 +28,9 @@
 #ifndef VQA_TILE_GROUP
 #define VQA_TILE_GROUP 4
 #endif
+#ifndef VQA_TILE_BITS
+#define VQA_TILE_BITS 12
+#endif
 #ifndef VQA_TILES_PER_WG
 #define VQA_TILES_PER_WG 1
 #endif
@@ -142,14 +145,18 @@ __global__ __launch_bounds__(kT) void k_diag(double2* st, int n, int C, int kind
 
 
 // ---- tiled passes -----------------------------------------------------------------
-constexpr int kTileBits = 12;                 // qubits of a tile
+constexpr int kTileBits = VQA_TILE_BITS;      // qubits of a tile
 constexpr int kTileAmps = 1 << kTileBits;
 constexpr int kTileLow = 4;                   // the lowest qubits belong to every tile (256-byte runs in HBM)
 constexpr int kGroup = VQA_TILE_GROUP;        // tile qubits held in a thread's registers during a sweep
 constexpr int kTT = kTileAmps >> kGroup;      // threads of a tile workgroup
 constexpr int kTA = 1 << kGroup;              // amplitudes per thread
 constexpr int kThreadBits = kTileBits - kGroup;
+#ifdef VQA_TILE_WAVES
+constexpr int kTileWaves = VQA_TILE_WAVES;
+#else
 constexpr int kTileWaves = 2 * (kTT / 64) / 4; // waves per SIMD with two workgroups on a CU (what their LDS allows)
+#endif
 constexpr int kGateBatch = 256;               // most gates in one pass
 constexpr int kMaxMats = 48;                  // most fused 2x2s in one pass (their matrices sit in LDS)
 constexpr int kMaxOps = 96;                   // most register operations in one pass
@@ -560,9 +567,11 @@ static bool group_sweeps(TilePlan::Pass& pass, const std::vector<TileGate>& in_o
     auto fits = [&](const HSweep& sw, int t) {
         if (std::find(sw.gpos.begin(), sw.gpos.end(), t) != sw.gpos.end()) return true;
         if ((int)sw.gpos.size() >= kGroup) return false;
-        int same = 0;   // at most two group positions per residue class mod 4 (see tile_slot)
+        // every residue class mod 4 keeps a position outside the group (see tile_slot)
+        int same = 0, members = 0;
         for (int p : sw.gpos) same += (p & 3) == (t & 3);
-        return same < 2;
+        for (int p = 0; p < kTileBits; ++p) members += (p & 3) == (t & 3);
+        return same + 1 < members;
     };
     for (const TileGate& tg : in_order) {
         const bool diag = tg.kind == VQA_GATE_RZ || tg.kind == VQA_GATE_Z || tg.kind == VQA_GATE_CZ || tg.kind == kGateZZ;
