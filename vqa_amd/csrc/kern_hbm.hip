@@ -40,7 +40,7 @@ namespace vqa {
 namespace {
 
 constexpr int kT = 256;
-constexpr int kZBatch = 16;  // Z-string terms (or marginal bins) reduced per pass
+constexpr int kZBatch = 32;  // Z-string terms (or marginal bins) reduced per pass
 
 struct HbmCommon {
     int n, n_ops, n_input;
