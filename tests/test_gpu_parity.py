@@ -392,6 +392,77 @@ def test_parameter_subset_sweep(n, d, builder):
     assert np.abs(eh[:, [0, 2 * mine[0] + 1, 2 * mine[1] + 2]] - full_e.cpu().numpy()[:, [0, 2 * mine[0] + 1, 2 * mine[1] + 2]]).max() < TOL
 
 
+def _edge_circuit(n, shared):
+    """Parameters with a coefficient, a parameter that drives no gate, (optionally) one shared by two
+    gates, CNOT sandwiches, input gates, rotations of every axis on low, middle and top qubits."""
+    from vqa_amd.circuit import SRC_THETA
+    c = LearningCircuit(n)
+    for q in range(n):
+        c.add_H_gate(q)
+        c.add_input_RZ_gate(q, lambda x, q=q: x[q % len(x)])
+    for q in range(n - 1):
+        c.add_CNOT_gate(q, q + 1)
+        c.add_input_RZ_gate(q + 1, lambda x, q=q: x[q % len(x)] * x[(q + 1) % len(x)])
+        c.add_CNOT_gate(q, q + 1)
+    for q in range(n):
+        c.add_parametric_RY_gate(q, 0.1 * q)
+        c.add_parametric_RZ_gate(q, 0.2)
+    c._theta.append(0.7)                                   # parameter 2n: drives nothing
+    for q in range(0, n, 2):
+        c.add_CZ_gate(q, (q + 1) % n)
+    first = None
+    for q in range(n):
+        pid = c.add_parametric_RX_gate(q, 0.3)
+        first = pid if first is None else first
+    if shared:
+        c.add_parametric_RY_gate(n - 1, 0.0, share_with=first, share_with_coef=-0.5)
+    # coefficients other than one on single-gate parameters
+    ops = c._ops
+    for k, op in enumerate(ops):
+        if op[3] == SRC_THETA and op[4] in (1, 2 * n + 2):
+            ops[k] = op[:6] + (2.0 if op[4] == 1 else -1.5, op[7])
+    c.add_CNOT_gate(n - 1, 0)
+    c.add_parametric_RY_gate(0, 0.4)
+    return c
+
+
+@pytest.mark.parametrize("shared", [False, True])
+def test_streaming_sweep_edge_cases(shared):
+    """The streaming engine's sweep (one moved state per parameter) on a circuit with scaled
+    parameters and one that drives no gate; with a parameter shared by two gates the call is
+    served by the explicit list.  A sample index beyond the batch gives NaN rows; an observable
+    without terms gives zeros."""
+    n = 14
+    c = _edge_circuit(n, shared)
+    rng = np.random.default_rng(17)
+    theta = rng.uniform(-3, 3, c.n_theta)
+    x = rng.uniform(0, np.pi, (3, 4))
+    ia = c.input_angles(x)
+    o1 = Observable(n); o1.add_operator(0.6, "Z 0 Z 13"); o1.add_operator(-0.2, "X 5"); o1.add_operator(0.3, "")
+    empty = Observable(n)
+    o2 = Observable(n); o2.add_operator(1.0, "Z 7")
+    obs = [o1, empty, o2]
+    sel = np.array([2, 0], np.int32)
+    si, sp, sv = cpu_oracle.psr_lists(2, c.n_theta, sel=sel)
+    want_e, want_m = cpu_oracle.eval_batch(c, theta, ia, si, sp, sv, obs_list=obs_tuples(obs), n_marg_bits=3)
+    got_e, got_m = c.psr_full(theta, ia, sel=sel, obs_list=obs, n_marg_bits=3)
+    assert np.abs(got_e.reshape(want_e.shape) - want_e).max() < TOL
+    assert np.abs(got_m.reshape(want_m.shape) - want_m).max() < TOL
+    assert np.all(got_e[:, :, 1] == 0.0)
+    K = 2 * c.n_theta + 1
+    unused = 2 * n
+    assert np.array_equal(got_e[:, 2 * unused + 1], got_e[:, 0]) and np.array_equal(got_e[:, 2 * unused + 2], got_e[:, 0])
+    # device path with a sample index that does not exist: its rows are NaN, the others are not
+    import torch
+    d_in = c.upload_inputs(x)
+    bad = torch.tensor([1, 7], dtype=torch.int32, device="cuda")
+    e2, m2 = c.psr_full(theta, d_in, sel=bad, obs_list=obs, n_marg_bits=3)
+    e2, m2 = e2.cpu().numpy(), m2.cpu().numpy()
+    assert np.isnan(e2[1]).all() and np.isnan(m2[1]).all()
+    assert np.isfinite(e2[0]).all() and np.isfinite(m2[0]).all()
+    assert e2.shape == (2, K, 3)
+
+
 def test_tiled_passes_against_gate_sweeps_22_qubits():
     """Beyond what the oracle finishes quickly: the tiled passes of the HBM engine against its
     one-sweep-per-gate form (independent kernels) on a 22-qubit circuit with all gate kinds."""
