@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--backend", default="nccl", help="process-group backend (gloo: rehearsals of the N > 1 path)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="create the process group even for one rank (exercises the RCCL calls on a one-GPU box)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="every rank on cuda:0 (rehearsal of the N > 1 path on a one-GPU box; not a valid number)")
     args = ap.parse_args()
@@ -98,8 +100,12 @@ def main():
     if args.share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
         else:
@@ -167,7 +173,7 @@ def main():
         return sharded_mse_gradient(timed, d_theta, d_in, d_y, w, z0, n_global=B * world, out_expect=d_out)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -179,7 +185,7 @@ def main():
         g = step(i)
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -220,7 +226,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(circ, theta, ia, P, args.cpu_seconds)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -64,7 +64,7 @@ def sharded_mse_gradient(circuit, theta, inputs, y, w, obs, n_global=None, group
         e = torch.from_numpy(e)
     y_t = y if isinstance(y, torch.Tensor) else torch.from_numpy(np.asarray(y, np.float64)).to(e.device)
     sums = mse_gradient_sums(e, y_t, w)
-    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    distributed = dist.is_available() and dist.is_initialized()
     if n_global is None:
         count = torch.tensor([float(e.shape[0])], dtype=torch.float64, device=e.device)
         if distributed:
