@@ -306,6 +306,22 @@ def test_sweep_with_shared_and_scaled_parameters():
     assert np.abs(got_m.reshape(want_m.shape) - want_m).max() < TOL
 
 
+def test_thirteen_qubits_automatic_engine():
+    """13 qubits are served by the streaming engine's tiles (two tiles per state) by default."""
+    c = create_ibm_HEA_ansatz(13, 2, seed=3)
+    rng = np.random.default_rng(13)
+    theta = rng.uniform(0, 2 * np.pi, c.n_theta)
+    x = rng.uniform(0, np.pi, (2, 13))
+    ia = c.input_angles(x)
+    z0 = Observable(13); z0.add_operator(1.0, "Z 0"); z0.add_operator(0.5, "Z 5 Z 12")
+    si, sp, sv = cpu_oracle.psr_lists(2, c.n_theta)
+    want_e, want_m = cpu_oracle.eval_batch(c, theta, ia, si, sp, sv, obs_list=obs_tuples([z0]), n_marg_bits=2)
+    got_e, got_m = c.psr_full(theta, ia, obs_list=[z0], n_marg_bits=2)
+    assert np.abs(got_e.reshape(want_e.shape) - want_e).max() < TOL
+    assert np.abs(got_m.reshape(want_m.shape) - want_m).max() < TOL
+    compare(c, theta, x, [z0], 2, si[:9], sp[:9], sv[:9])
+
+
 def test_twenty_qubit_streaming_engine():
     """The 20-qubit configuration's shape on the HBM engine (automatic choice)."""
     c = create_ibm_HEA_ansatz(20, 1, seed=1)

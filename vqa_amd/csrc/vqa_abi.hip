@@ -359,7 +359,9 @@ int vqa_circuit_create(int n_qubits, const vqa_op* ops, int n_ops, int n_theta, 
             engine = 2;
         }
     }
-    if (engine == 0) engine = n_qubits <= lds_engine_max_qubits() ? 1 : 3;
+    // automatic: the LDS engine below the streaming engine's tiles (13 qubits: its sweeps are 12x
+    // the LDS engine's there)
+    if (engine == 0) engine = n_qubits <= 12 ? 1 : 3;
     if ((engine == 1 || engine == 2) && n_qubits > lds_engine_max_qubits())
         VQA_FAIL(VQA_EUNSUPPORTED, "the workgroup-resident engines hold at most %d qubits", lds_engine_max_qubits());
     vqa_circuit* c = new (std::nothrow) vqa_circuit();
