@@ -307,7 +307,8 @@ def test_sweep_with_shared_and_scaled_parameters():
 
 
 def test_thirteen_qubits_automatic_engine():
-    """13 qubits are served by the streaming engine's tiles (two tiles per state) by default."""
+    """13 qubits, automatic engine choice: the register engine (512 threads per state) for Z-basis
+    calls, the streaming engine's tiles (two per state) when the call has X/Y terms."""
     c = create_ibm_HEA_ansatz(13, 2, seed=3)
     rng = np.random.default_rng(13)
     theta = rng.uniform(0, 2 * np.pi, c.n_theta)
@@ -320,6 +321,11 @@ def test_thirteen_qubits_automatic_engine():
     assert np.abs(got_e.reshape(want_e.shape) - want_e).max() < TOL
     assert np.abs(got_m.reshape(want_m.shape) - want_m).max() < TOL
     compare(c, theta, x, [z0], 2, si[:9], sp[:9], sv[:9])
+    xy = Observable(13); xy.add_operator(0.4, "X 2 Y 9"); xy.add_operator(0.6, "Z 1"); xy.add_operator(-0.3, "X 12")
+    compare(c, theta, x, [xy, z0], 2, si[:9], sp[:9], sv[:9])
+    got_x, _ = c.psr_full(theta, ia, obs_list=[xy])
+    want_x, _ = cpu_oracle.eval_batch(c, theta, ia, si, sp, sv, obs_list=obs_tuples([xy]))
+    assert np.abs(got_x.reshape(want_x.shape) - want_x).max() < TOL
 
 
 def test_twenty_qubit_streaming_engine():

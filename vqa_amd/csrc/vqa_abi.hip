@@ -228,11 +228,11 @@ static int run_call(EvalCall& call, DeviceCtx* ctx) {
     VQA_HIP(hipSetDevice(call.device));
     int engine = resolve_engine(call.c);
     if (engine == 2) {
-        // engine 2 measures in the Z basis only; X/Y Pauli terms and wide
-        // marginals go to the gate-by-gate LDS engine (same results)
+        // engine 2 measures in the Z basis only; X/Y Pauli terms and wide marginals go to the
+        // gate-by-gate LDS engine (13 qubits: to the streaming engine); same results
         bool z_only = call.n_marg_bits <= 6;
         for (int t = 0; t < call.obs.n_terms; ++t) z_only &= call.obs.x[t] == 0;
-        if (!z_only) engine = 1;
+        if (!z_only) engine = call.c->n_qubits <= 12 ? 1 : 3;
     }
     switch (engine) {
     case 1: return lds_engine_run(call);
@@ -348,7 +348,7 @@ int vqa_circuit_create(int n_qubits, const vqa_op* ops, int n_ops, int n_theta, 
     }
     int engine = g_engine;
     std::shared_ptr<RegProgram> reg;
-    if ((engine == 0 && n_qubits >= kRegBits && n_qubits <= 12) || engine == 2) {
+    if ((engine == 0 && n_qubits >= kRegBits && n_qubits <= 13) || engine == 2) {
         reg = std::make_shared<RegProgram>();
         std::string why;
         std::vector<vqa_op> v(ops, ops + n_ops);
@@ -359,8 +359,8 @@ int vqa_circuit_create(int n_qubits, const vqa_op* ops, int n_ops, int n_theta, 
             engine = 2;
         }
     }
-    // automatic: the LDS engine below the streaming engine's tiles (13 qubits: its sweeps are 12x
-    // the LDS engine's there)
+    // automatic, when the register engine does not take the circuit: the LDS engine below the
+    // streaming engine's tiles (at 13 qubits its sweeps are 12x the LDS engine's)
     if (engine == 0) engine = n_qubits <= 12 ? 1 : 3;
     if ((engine == 1 || engine == 2) && n_qubits > lds_engine_max_qubits())
         VQA_FAIL(VQA_EUNSUPPORTED, "the workgroup-resident engines hold at most %d qubits", lds_engine_max_qubits());
