@@ -325,12 +325,22 @@ def cpu_baseline(circ, theta, ia, P, seconds):
     t0 = time.perf_counter()
     cpu_oracle.eval_batch(circ, theta, ia, si, sp, sv, obs_list=[z0], n_threads=threads)
     dt = time.perf_counter() - t0
+    # the reference's own CPU path is qulacs + skqulacs: say whether this box has them (never installed here)
+    try:
+        import qulacs  # noqa: F401
+        import skqulacs  # noqa: F401
+
+        ref_note = ("qulacs %s present but not timed: the baseline below is the port"
+                    % getattr(qulacs, "__version__", "?"))
+    except ImportError:
+        ref_note = "qulacs / skqulacs not present on this box: the reference's CPU path cannot be timed, the port is"
     return {
         "value": n_eval / dt / K,
         "unit": "gradients/s",
         "circuit_evals_per_sec": n_eval / dt,
         "cores": threads,
         "kind": "port",
+        "reference_cpu_path": ref_note,
         "sample": f"{n_eval} circuit evaluations (first {n_s} samples of the same batch, same shifts), "
                   f"{threads} OpenMP threads, {dt:.1f} s",
     }
