@@ -485,6 +485,55 @@ def test_streaming_sweep_edge_cases(shared):
     assert e2.shape == (2, K, 3)
 
 
+@pytest.mark.parametrize("n,shared", [(6, False), (7, True), (8, False), (9, True)])
+def test_grouped_small_sweeps(n, shared):
+    """Below 10 qubits the register engine runs a sweep as groups of shifts of one sample that share
+    the sample's prepared tables (each state patches the entries of its own parameter).  Scaled
+    parameters, one that drives no gate, one shared by two fused 2x2s; against the oracle and against
+    the same kernel family run as an explicit list; parameter subsets; an invalid sample index."""
+    import os
+    import torch
+    set_engine("reg")
+    c = _edge_circuit(n, shared)
+    rng = np.random.default_rng(n)
+    theta = rng.uniform(-3, 3, c.n_theta)
+    x = rng.uniform(0, np.pi, (5, 4))
+    ia = c.input_angles(x)
+    o1 = Observable(n); o1.add_operator(0.6, f"Z 0 Z {n - 1}"); o1.add_operator(0.3, "")
+    o2 = Observable(n); o2.add_operator(1.0, f"Z {n // 2}")
+    obs = [o1, Observable(n), o2]
+    sel = np.array([4, 0, 2], np.int32)
+    si, sp, sv = cpu_oracle.psr_lists(3, c.n_theta, sel=sel)
+    want_e, want_m = cpu_oracle.eval_batch(c, theta, ia, si, sp, sv, obs_list=obs_tuples(obs), n_marg_bits=3)
+    got_e, got_m = c.psr_full(theta, ia, sel=sel, obs_list=obs, n_marg_bits=3)
+    assert np.abs(got_e.reshape(want_e.shape) - want_e).max() < TOL
+    assert np.abs(got_m.reshape(want_m.shape) - want_m).max() < TOL
+    unused = 2 * n
+    assert np.array_equal(got_e[:, 2 * unused + 1], got_e[:, 0]) and np.array_equal(got_e[:, 2 * unused + 2], got_e[:, 0])
+    os.environ["VQA_NO_GROUP"] = "1"
+    try:
+        plain_e, plain_m = c.psr_full(theta, ia, sel=sel, obs_list=obs, n_marg_bits=3)
+    finally:
+        del os.environ["VQA_NO_GROUP"]
+    assert np.abs(plain_e - got_e).max() < 1e-13 and np.abs(plain_m - got_m).max() < 1e-13
+    # a single-qubit observable: parameters outside its light cone are copied, not run
+    z0 = Observable(n); z0.add_operator(1.0, f"Z {n // 2}")
+    d_in = c.upload_inputs(x)
+    full_e, full_m = c.psr_full(theta, d_in, obs_list=[z0], n_marg_bits=0)
+    si5, sp5, sv5 = cpu_oracle.psr_lists(5, c.n_theta)
+    want5, _ = cpu_oracle.eval_batch(c, theta, ia, si5, sp5, sv5, obs_list=obs_tuples([z0]))
+    assert np.abs(full_e.cpu().numpy().reshape(want5.shape) - want5).max() < TOL
+    mine = np.arange(0, c.n_theta, 3)
+    e, _ = c.psr_full(theta, d_in, obs_list=[z0], params=mine)
+    rows = np.concatenate([[0], 2 * mine + 1, 2 * mine + 2])
+    assert float((e[:, rows] - full_e[:, rows]).abs().max()) < TOL
+    bad = torch.tensor([1, 9], dtype=torch.int32, device="cuda")
+    e2, m2 = c.psr_full(theta, d_in, sel=bad, obs_list=obs, n_marg_bits=3)
+    e2, m2 = e2.cpu().numpy(), m2.cpu().numpy()
+    assert np.isnan(e2[1]).all() and np.isnan(m2[1]).all()
+    assert np.isfinite(e2[0]).all() and np.isfinite(m2[0]).all()
+
+
 def test_tiled_passes_against_gate_sweeps_22_qubits():
     """Beyond what the oracle finishes quickly: the tiled passes of the HBM engine against its
     one-sweep-per-gate form (independent kernels) on a 22-qubit circuit with all gate kinds."""

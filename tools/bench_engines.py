@@ -28,6 +28,15 @@ for eng in [int(v) for v in sys.argv[4:]] or [1, 2, 3]:
         dt = time.perf_counter() - t0
         print(f"n={n} d={d} engine {eng}: {B / dt:10.1f} gradients/s ({B * (2 * c.n_theta + 1) / dt:12.0f} evaluations/s), "
               f"<Z0>[0,0]={float(e[0, 0, 0]):+.10f}", flush=True)
+        c.eval_batch(theta, x[:2], obs_list=obs)
+        torch.cuda.synchronize()
+        reps = max(1, (1 << 20) // B)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            c.eval_batch(theta, x, obs_list=obs)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(f"n={n} d={d} engine {eng}: {reps * B / dt:12.0f} plain evaluations/s (explicit list of {B}, {reps} calls)", flush=True)
     except _lib.VqaError as err:
         print(f"n={n} d={d} engine {eng}: {err}", flush=True)
 _lib.lib().vqa_set_engine(0)

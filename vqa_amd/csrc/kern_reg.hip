@@ -986,6 +986,167 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : VQA_WAVES) void k_reg_eva
     }
 }
 
+// ---- full parameter-shift sweeps of small circuits (several states per workgroup) ------
+// Below 10 qubits a workgroup (one wave) holds S = 64 / 2^(n-4) states.  As an explicit list
+// every instance would prepare all its fused 2x2s from scratch, which costs far more than the
+// gates of so small a state.  Here the S states of a workgroup are S shifts of ONE sample:
+// the unshifted tables of the sample are prepared once (and kept while the workgroup stays on
+// that sample), copied to every state, and the thread of each state patches the entries its
+// parameter enters: the fused 2x2 recomputed at the shifted angle, the phase slots in front of
+// and behind it multiplied by the ratio of new and old RZ factors, or the parameter's own
+// phase slot turned by half the shift.
+// a.E = number of samples; a.live[0 .. n_live) = the shift indices k to run (0 = unshifted,
+// 2i+1 / 2i+2 = +-shift of parameter i), ascending; output instance j * (2P+1) + k.
+// Work items (sample, chunk of S shifts) are dealt to the workgroups in contiguous ranges.
+template <bool SCALED>
+__device__ __forceinline__ void prep_base(const RegArgs& a, const Prog& pp, double2* base, double2* bag,
+                                          const double* row, int NU, int N1, int N2, int tid, int nthr) {
+    for (int k = tid; k < N1 + N2; k += nthr) {
+        const int begin = k < N1 ? pp.d1[k].begin : pp.d2[k - N1].begin;
+        const int count = k < N1 ? pp.d1[k].count : pp.d2[k - N1].count;
+        cplx ph = { 1.0, 0.0 };
+        if (count > 0) {
+            double ang = 0.0;
+            for (int j = 0; j < count; ++j) ang += elem_angle_c(pp.terms + begin + j, a.theta, row, -1, 0.0);
+            double sn, c;
+            sincos(0.5 * ang, &sn, &c);
+            ph = { c, sn };
+        }
+        base[NU + k] = make_double2(ph.x, ph.y);
+    }
+    // even U-stages first: no two entries of one round update the same phase slot
+    for (int parity = 0; parity < 2; ++parity) {
+        __syncthreads();
+        for (int u = tid; u < NU; u += nthr) {
+            if (pp.uent[u].parity != parity) continue;
+            const int d_before = pp.uent[u].d_before, d_after = pp.uent[u].d_after;
+            double2 cs;
+            cplx A, G, gp;
+            compute_uentry<SCALED>(pp, u, a.theta, row, -1, 0.0, -1, cs, A, G, gp);
+            base[u] = cs;
+            bag[2 * u] = make_double2(A.x, A.y);
+            bag[2 * u + 1] = make_double2(G.x, G.y);
+            if (d_before >= 0) {
+                const double2 p = base[NU + d_before];
+                const cplx q = cmul({ p.x, p.y }, G);
+                base[NU + d_before] = make_double2(q.x, q.y);
+            }
+            if (d_after >= 0) {
+                const double2 p = base[NU + d_after];
+                const cplx q = cmul({ p.x, p.y }, A);
+                base[NU + d_after] = make_double2(q.x, q.y);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(64, VQA_WAVES) void k_reg_group(RegArgs a) {
+    constexpr int BLOCK = 64;
+    constexpr bool SCALED = false;   // several states per wave: plain (cos, sin) lane rotations
+    extern __shared__ double2 smem[];
+    const Prog pp = load_prog(a.prog);
+    const int n = pp.H->n, T = pp.H->T, S = pp.H->S;
+    const int NU = pp.H->n_uent, N1 = pp.H->n_d1, N2 = pp.H->n_d2;
+    const int tab_stride = NU + N1 + N2;
+    const int tid = threadIdx.x;
+    const int sl = tid >> T;
+    const int t = tid & ((1 << T) - 1);
+
+    double2* tabs = smem;                                  // S * tab_stride
+    double2* base = tabs + (size_t)S * tab_stride;         // unshifted tables of the current sample
+    double2* bag = base + tab_stride;                      // (A, G) of every fused 2x2 of the unshifted circuit
+    double2* xbuf = bag + 2 * (size_t)NU;
+    double* red = (double*)(xbuf + (pp.H->has_xpose ? ((size_t)1 << (n - 1)) : 0));
+    unsigned short* smask = (unsigned short*)(red + 64);
+
+    Ctx cx;
+    cx.mat = tabs + (size_t)sl * tab_stride;
+    cx.ph1 = cx.mat + NU;
+    cx.ph2 = cx.ph1 + N1;
+    cx.xbuf = (char*)xbuf;
+    cx.smask = smask;
+    cx.T = T; cx.nthr = BLOCK;
+    cx.wave = 0; cx.tmask = (1 << T) - 1;
+    cx.xc_id = -1; cx.xc_wt = 0; cx.xc_rt = 0;
+    cx.area = __builtin_amdgcn_make_buffer_rsrc((void*)nullptr, 0, 0, 0x00020000);
+    cx.image_bytes = 0;
+#ifdef VQA_PROF
+    cx.flag_mask = -1;
+#endif
+    thread_constants<BLOCK>(pp, smask, T, t, tid);
+
+    const int K = 2 * a.spec.P + 1;
+    const int NL = a.n_live;
+    const int chunks = (NL + S - 1) / S;
+    const int64_t total = a.E * chunks;
+    const int64_t w0 = total * blockIdx.x / gridDim.x, w1 = total * (blockIdx.x + 1) / gridDim.x;
+    int64_t cur = -1;
+    unsigned parity = 0;
+    for (int64_t w = w0; w < w1; ++w) {
+        const int64_t j = w / chunks;
+        const int ch = (int)(w - j * chunks);
+        int b = a.spec.sel ? a.spec.sel[j] : (int)j;
+        const bool valid = a.spec.B == 0 || (unsigned)b < (unsigned)a.spec.B;
+        if (!valid) b = 0;
+        const double* row = a.input + (size_t)b * a.n_input;
+        __syncthreads();   // the previous item is done with the tables
+        if (j != cur) {
+            prep_base<SCALED>(a, pp, base, bag, row, NU, N1, N2, tid, BLOCK);
+            cur = j;
+            __syncthreads();
+        }
+        for (int i = tid; i < S * tab_stride; i += BLOCK) {
+            const int s2 = i / tab_stride;
+            tabs[i] = base[i - s2 * tab_stride];
+        }
+        __syncthreads();
+        const int li = ch * S + sl;
+        const bool live = li < NL;
+        const int k = live ? a.live[li] : 0;
+        if (live && t == 0 && k > 0) {
+            const int i = (k - 1) >> 1;
+            const double sval = (k & 1) ? a.spec.shift : -a.spec.shift;
+            double2* tb = tabs + (size_t)sl * tab_stride;
+            const int rb = pp.params[i].ref_begin, rcnt = pp.params[i].ref_count;
+            for (int q = 0; q < rcnt; ++q) {
+                const int kind = pp.refs[rb + q].kind, index = pp.refs[rb + q].index;
+                if (kind == 0) {
+                    double2 m;
+                    cplx A, G, gp;
+                    compute_uentry<SCALED>(pp, index, a.theta, row, i, sval, -1, m, A, G, gp);
+                    tb[index] = m;
+                    const int d_before = pp.uent[index].d_before, d_after = pp.uent[index].d_after;
+                    if (d_before >= 0) {
+                        const double2 g0 = bag[2 * index + 1], p = tb[NU + d_before];
+                        const cplx f = cmul(cconj({ g0.x, g0.y }), G), r = cmul({ p.x, p.y }, f);
+                        tb[NU + d_before] = make_double2(r.x, r.y);
+                    }
+                    if (d_after >= 0) {
+                        const double2 a0 = bag[2 * index], p = tb[NU + d_after];
+                        const cplx f = cmul(cconj({ a0.x, a0.y }), A), r = cmul({ p.x, p.y }, f);
+                        tb[NU + d_after] = make_double2(r.x, r.y);
+                    }
+                } else {
+                    double sn, c;
+                    sincos(0.5 * pp.refs[rb + q].coef_sum * sval, &sn, &c);
+                    const int slot = kind == 1 ? NU + index : NU + N1 + index;
+                    const double2 p = tb[slot];
+                    const cplx r = cmul({ p.x, p.y }, { c, sn });
+                    tb[slot] = make_double2(r.x, r.y);
+                }
+            }
+        }
+        __syncthreads();
+
+        double2 amp[kRegAmps];
+#pragma unroll
+        for (int r = 0; r < kRegAmps; ++r) amp[r] = make_double2(0.0, 0.0);
+        if (t == 0) amp[0].x = 1.0;
+        run_phases<SCALED>(amp, pp, cx, 0, false, false);
+        measure(amp, a, pp, cx, red, parity, j * K + k, live, valid, nullptr);
+    }
+}
+
 // ---- full parameter-shift sweeps ------------------------------------------------------
 // a.E = number of samples; sample j = sel[j] (or j); outputs at instance
 // j * (2P+1) + k.  One state per workgroup (BLOCK = 2^T >= 64 threads).
@@ -1333,6 +1494,76 @@ int reg_engine_sweep(const EvalCall& call, const void* d_prog, const RegProgram&
         if (rc) return rc;
         if (call.n_marg_bits > 0)
             rc = fill_dead_rows(call.stream, call.d_out_marginal, n_samples, K, 1 << call.n_marg_bits, d_dead, n_dead);
+        if (rc) return rc;
+    }
+    if (call.param_mask) VQA_HIP(hipStreamSynchronize(call.stream));
+    return VQA_OK;
+}
+
+// Grouped sweeps of small circuits (k_reg_group): several states per workgroup and the tables fit.
+static size_t group_lds_bytes(const RegProgram& P) {
+    return P.lds_bytes + ((size_t)P.hdr.n_uent * 3 + P.hdr.n_d1 + P.hdr.n_d2) * 16;
+}
+bool reg_engine_can_group(const RegProgram& P) {
+    return P.hdr.S > 1 && P.hdr.block == 64 && group_lds_bytes(P) <= 160 * 1024;
+}
+
+int reg_engine_group(const EvalCall& call, const void* d_prog, const RegProgram& P, int n_samples) {
+    int rc = check_reg_call(call);
+    if (rc) return rc;
+    if (n_samples <= 0) return VQA_OK;
+    RegArgs a = make_args(call, d_prog);
+    a.E = n_samples;
+    // the shift indices to run: the unshifted circuit and both shifts of every parameter that can
+    // matter for this call's observables; the rows of the others are copies of the unshifted row
+    ConeInfo& cone = *call.cone;
+    {
+        std::lock_guard<std::mutex> lk(call.c->mu);
+        if (!cone.group_built) {
+            cone.group_live_k.push_back(0);
+            for (int i = 0; i < call.c->n_theta; ++i)
+                if (!cone.dead[i]) { cone.group_live_k.push_back(2 * i + 1); cone.group_live_k.push_back(2 * i + 2); }
+            cone.group_built = true;
+        }
+    }
+    std::vector<int32_t> m_live, m_dead;
+    if (call.param_mask) {
+        m_live.push_back(0);
+        for (int i = 0; i < call.c->n_theta; ++i) {
+            if (!call.param_mask[i]) continue;
+            if (cone.dead[i]) m_dead.push_back(i);
+            else { m_live.push_back(2 * i + 1); m_live.push_back(2 * i + 2); }
+        }
+    }
+    const std::vector<int32_t>& live_k = call.param_mask ? m_live : cone.group_live_k;
+    const std::vector<int32_t>& dead_list = call.param_mask ? m_dead : cone.dead_list;
+    const size_t n_live = live_k.size(), n_dead = dead_list.size();
+    void* ws = nullptr;
+    rc = workspace_get(call.device, (n_live + n_dead) * sizeof(int32_t) + 256, &ws);
+    if (rc) return rc;
+    int32_t* d_live = (int32_t*)ws;
+    int32_t* d_dead = d_live + n_live;
+    // (the cached lists live as long as the circuit; a per-call list is waited for below)
+    VQA_HIP(hipMemcpyAsync(d_live, live_k.data(), n_live * sizeof(int32_t), hipMemcpyHostToDevice, call.stream));
+    if (n_dead)
+        VQA_HIP(hipMemcpyAsync(d_dead, dead_list.data(), n_dead * sizeof(int32_t), hipMemcpyHostToDevice, call.stream));
+    a.live = d_live;
+    a.n_live = (int)n_live;
+    const size_t lds = group_lds_bytes(P);
+    VQA_HIP(hipFuncSetAttribute((const void*)k_reg_group, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int S = P.hdr.S;
+    const int64_t items = (int64_t)n_samples * (int64_t)((n_live + S - 1) / S);
+    const int by_lds = (int)((160 * 1024) / std::max<size_t>(lds, 1));
+    const int per_cu = std::max(1, std::min(VQA_WAVES * 4, by_lds));
+    const int grid = (int)std::min<int64_t>(items, (int64_t)256 * per_cu);
+    hipLaunchKernelGGL(k_reg_group, dim3(grid), dim3(64), lds, call.stream, a);
+    VQA_HIP(hipGetLastError());
+    if (n_dead) {
+        const int K = 2 * call.c->n_theta + 1;
+        rc = fill_dead_rows(call.stream, call.d_out_expect, n_samples, K, call.obs.n_obs, d_dead, (int)n_dead);
+        if (rc) return rc;
+        if (call.n_marg_bits > 0)
+            rc = fill_dead_rows(call.stream, call.d_out_marginal, n_samples, K, 1 << call.n_marg_bits, d_dead, (int)n_dead);
         if (rc) return rc;
     }
     if (call.param_mask) VQA_HIP(hipStreamSynchronize(call.stream));

@@ -233,6 +233,10 @@ static int run_call(EvalCall& call, DeviceCtx* ctx) {
         bool z_only = call.n_marg_bits <= 6;
         for (int t = 0; t < call.obs.n_terms; ++t) z_only &= call.obs.x[t] == 0;
         if (!z_only) engine = call.c->n_qubits <= 12 ? 1 : 3;
+        // automatic choice at 4 and 5 qubits (a state is a thread or two): sweeps stay here (their
+        // groups share the prepared tables: 2x to 6x the LDS engine), explicit lists, where every
+        // instance prepares all its fused 2x2s, go to the LDS engine (2x to 4x this one)
+        else if (call.c->auto_engine && call.c->n_qubits <= 5 && !(call.spec.psr && call.n_sweep > 0)) engine = 1;
     }
     switch (engine) {
     case 1: return lds_engine_run(call);
@@ -249,6 +253,8 @@ static int run_call(EvalCall& call, DeviceCtx* ctx) {
             void* d_prog = ctx->reg_prog;
             int rc = cone_reg_program(call, &prog, &d_prog);
             if (rc) return rc;
+            if (call.spec.psr && call.n_sweep > 0 && call.cone && reg_engine_can_group(*prog) && !getenv("VQA_NO_GROUP"))
+                return reg_engine_group(call, d_prog, *prog, call.n_sweep);
             return reg_engine_run(call, d_prog, *prog);
         }
     case 3:
@@ -372,6 +378,7 @@ int vqa_circuit_create(int n_qubits, const vqa_op* ops, int n_ops, int n_theta, 
     c->n_theta = n_theta;
     c->n_input = n_input;
     c->engine = engine;
+    c->auto_engine = g_engine == 0;
     c->ops.assign(ops, ops + n_ops);
     *out = c;
     return VQA_OK;

@@ -134,6 +134,8 @@ struct ConeInfo {
     std::vector<int32_t> dead_list;          // the dead parameters, ascending
     bool reg_built = false;
     std::vector<int32_t> reg_live_runs;      // engine 2: runs of the live parameters, in run order
+    bool group_built = false;
+    std::vector<int32_t> group_live_k;       // engine 2, small circuits: shift indices of the live parameters (0 first)
     bool hbm_built = false;
     std::vector<int32_t> hbm_ord, hbm_ord_pass, hbm_unused;   // engine 3: the sweep plan's lists without the dead
     std::vector<double> hbm_coef;
@@ -143,6 +145,7 @@ struct ConeInfo {
 struct vqa_circuit {
     int n_qubits, n_ops, n_theta, n_input;
     int engine;  // resolved engine: 1 LDS, 2 register-blocked, 3 HBM
+    bool auto_engine;  // the engine was chosen by the library (vqa_set_engine(0) at creation)
     std::vector<vqa_op> ops;
     std::shared_ptr<vqa::RegProgram> reg;  // host copy of the engine-2 program (may be null)
     std::shared_ptr<void> hbm_plan;        // engine 3: the gate list cut into tiled passes (built on first use)
@@ -178,6 +181,8 @@ int lds_engine_max_qubits();
 int reg_engine_run(const EvalCall& call, const void* d_prog, const RegProgram& prog);
 bool reg_engine_can_sweep(const RegProgram& prog);
 int reg_engine_sweep(const EvalCall& call, const void* d_prog, const RegProgram& prog, int n_samples);
+bool reg_engine_can_group(const RegProgram& prog);
+int reg_engine_group(const EvalCall& call, const void* d_prog, const RegProgram& prog, int n_samples);
 int hbm_engine_run(const EvalCall& call);
 bool hbm_engine_can_sweep(const EvalCall& call);
 int hbm_engine_sweep(const EvalCall& call, int n_samples);
