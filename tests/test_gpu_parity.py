@@ -79,7 +79,7 @@ def test_random_circuits_all_gate_kinds(engine, n):
 
 
 @pytest.mark.parametrize("engine,n,d", [("reg", 4, 2), ("reg", 6, 5), ("reg", 9, 2), ("reg", 11, 2), ("reg", 12, 2),
-                                        ("reg", 12, 10), ("reg", 13, 1),
+                                        ("reg", 12, 10), ("reg", 13, 1), ("reg", 14, 1),
                                         ("lds", 4, 2), ("lds", 6, 5), ("lds", 12, 2), ("lds", 13, 1),
                                         ("hbm", 6, 2), ("hbm", 14, 1), ("hbm", 16, 1), ("hbm", 17, 2), ("pergate", 14, 1)])
 def test_ibm_hea_full_parameter_shift(engine, n, d):
@@ -306,22 +306,23 @@ def test_sweep_with_shared_and_scaled_parameters():
     assert np.abs(got_m.reshape(want_m.shape) - want_m).max() < TOL
 
 
-def test_thirteen_qubits_automatic_engine():
-    """13 qubits, automatic engine choice: the register engine (512 threads per state) for Z-basis
-    calls, the streaming engine's tiles (two per state) when the call has X/Y terms."""
-    c = create_ibm_HEA_ansatz(13, 2, seed=3)
+@pytest.mark.parametrize("n", [13, 14])
+def test_thirteen_fourteen_qubits_automatic_engine(n):
+    """13 and 14 qubits, automatic engine choice: the register engine (512 / 1024 threads per state)
+    for Z-basis calls, the streaming engine's tiles (two / four per state) when the call has X/Y terms."""
+    c = create_ibm_HEA_ansatz(n, 2, seed=3)
     rng = np.random.default_rng(13)
     theta = rng.uniform(0, 2 * np.pi, c.n_theta)
-    x = rng.uniform(0, np.pi, (2, 13))
+    x = rng.uniform(0, np.pi, (2, n))
     ia = c.input_angles(x)
-    z0 = Observable(13); z0.add_operator(1.0, "Z 0"); z0.add_operator(0.5, "Z 5 Z 12")
+    z0 = Observable(n); z0.add_operator(1.0, "Z 0"); z0.add_operator(0.5, "Z 5 Z 12")
     si, sp, sv = cpu_oracle.psr_lists(2, c.n_theta)
     want_e, want_m = cpu_oracle.eval_batch(c, theta, ia, si, sp, sv, obs_list=obs_tuples([z0]), n_marg_bits=2)
     got_e, got_m = c.psr_full(theta, ia, obs_list=[z0], n_marg_bits=2)
     assert np.abs(got_e.reshape(want_e.shape) - want_e).max() < TOL
     assert np.abs(got_m.reshape(want_m.shape) - want_m).max() < TOL
     compare(c, theta, x, [z0], 2, si[:9], sp[:9], sv[:9])
-    xy = Observable(13); xy.add_operator(0.4, "X 2 Y 9"); xy.add_operator(0.6, "Z 1"); xy.add_operator(-0.3, "X 12")
+    xy = Observable(n); xy.add_operator(0.4, "X 2 Y 9"); xy.add_operator(0.6, "Z 1"); xy.add_operator(-0.3, "X 12")
     compare(c, theta, x, [xy, z0], 2, si[:9], sp[:9], sv[:9])
     got_x, _ = c.psr_full(theta, ia, obs_list=[xy])
     want_x, _ = cpu_oracle.eval_batch(c, theta, ia, si, sp, sv, obs_list=obs_tuples([xy]))
@@ -391,7 +392,7 @@ def test_streaming_sweep_with_pauli_sums(n, d):
     assert np.abs(got_e2 - want_e[:7]).max() < 1e-9
 
 
-@pytest.mark.parametrize("n,d,builder", [(12, 2, create_ibm_HEA_ansatz), (14, 2, create_ry_cz_ansatz)])
+@pytest.mark.parametrize("n,d,builder", [(8, 2, create_ibm_HEA_ansatz), (12, 2, create_ibm_HEA_ansatz), (14, 2, create_ry_cz_ansatz), (15, 2, create_ry_cz_ansatz)])
 def test_parameter_subset_sweep(n, d, builder):
     """vqa_psr_params_dev: the rows of the requested parameters (dead ones included) and the
     unshifted row equal the full sweep's; register engine and streaming engine."""

@@ -1,4 +1,4 @@
-// Engine 2: register-blocked fused statevector kernels (4 <= n <= 13).
+// Engine 2: register-blocked fused statevector kernels (4 <= n <= 14).
 //
 // The state of one circuit instance lives in the VGPRs of 2^(n-4) threads, 16
 // complex128 amplitudes per thread.  The program compiled by reg_compile.cpp is
@@ -707,17 +707,17 @@ __device__ __forceinline__ void state_sum(double (&v)[NV], const Ctx& cx, double
     for (int k = 0; k < NV; ++k) v[k] = wave_sum(v[k]);
     if (cx.T > 6) {
         const int wave = cx.wave, nwave = cx.nthr >> 6;
-        double* buf = red + (parity & 1u) * 32;
+        double* buf = red + (parity & 1u) * 64;
         parity = __builtin_amdgcn_readfirstlane(parity ^ 1u);   // (uniform: lives in a scalar register)
         if (cx.lane() == 0) {
 #pragma unroll
-            for (int k = 0; k < NV; ++k) buf[k * 8 + wave] = v[k];
+            for (int k = 0; k < NV; ++k) buf[k * 16 + wave] = v[k];
         }
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             v[k] = 0.0;
-            for (int w = 0; w < nwave; ++w) v[k] += buf[k * 8 + w];
+            for (int w = 0; w < nwave; ++w) v[k] += buf[k * 16 + w];
         }
     }
 }
@@ -929,7 +929,7 @@ __device__ __forceinline__ void thread_constants(const Prog& pp, unsigned short*
 
 // ---- explicit instance list ----------------------------------------------------------
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : VQA_WAVES) void k_reg_eval(RegArgs a) {
+__global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : BLOCK == 512 ? 2 : VQA_WAVES) void k_reg_eval(RegArgs a) {
     // blocks above one wave hold a single state: the scaled lane rotations apply
     constexpr bool SCALED = BLOCK > 64;
     extern __shared__ double2 smem[];
@@ -943,8 +943,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : VQA_WAVES) void k_reg_eva
 
     double2* tabs = smem;                                 // S * tab_stride
     double2* xbuf = tabs + (size_t)S * tab_stride;        // 2^(n-1) slots when the program transposes
-    double* red = (double*)(xbuf + (pp.H->has_xpose ? ((size_t)1 << (n - 1)) : 0));  // 64 doubles
-    unsigned short* smask = (unsigned short*)(red + 64);  // n_sign * BLOCK
+    double* red = (double*)(xbuf + (pp.H->has_xpose ? ((size_t)1 << (n - 1)) : 0));  // 128 doubles
+    unsigned short* smask = (unsigned short*)(red + 128);  // n_sign * BLOCK
 
     Ctx cx;
     cx.mat = tabs + (size_t)sl * tab_stride;
@@ -1057,7 +1057,7 @@ __global__ __launch_bounds__(64, VQA_WAVES) void k_reg_group(RegArgs a) {
     double2* bag = base + tab_stride;                      // (A, G) of every fused 2x2 of the unshifted circuit
     double2* xbuf = bag + 2 * (size_t)NU;
     double* red = (double*)(xbuf + (pp.H->has_xpose ? ((size_t)1 << (n - 1)) : 0));
-    unsigned short* smask = (unsigned short*)(red + 64);
+    unsigned short* smask = (unsigned short*)(red + 128);
 
     Ctx cx;
     cx.mat = tabs + (size_t)sl * tab_stride;
@@ -1211,7 +1211,7 @@ __device__ __forceinline__ void make_run_record(const RegArgs& a, const Prog& pp
 }
 
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : VQA_WAVES) void k_reg_psr(RegArgs a) {
+__global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : BLOCK == 512 ? 2 : VQA_WAVES) void k_reg_psr(RegArgs a) {
     extern __shared__ double2 smem[];
     const Prog pp = load_prog(a.prog);
     const int n = pp.H->n, T = pp.H->T;
@@ -1223,7 +1223,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 2 : VQA_WAVES) void k_reg_psr
     double2* tabs = smem;
     double2* xbuf = tabs + (size_t)(NU + N1 + N2);
     double* red = (double*)(xbuf + (pp.H->has_xpose ? ((size_t)1 << (n - 1)) : 0));
-    double2* pz = (double2*)(red + 64);                   // the current run's record (8 entries)
+    double2* pz = (double2*)(red + 128);                   // the current run's record (8 entries)
     double2* sav = pz + 8;                                // what the current patch replaced (3 entries, thread 0's)
     double* basev = (double*)(pz + 16);                   // the unshifted values (79 entries), squared norm of psi
     unsigned short* smask = (unsigned short*)(basev + 80);
@@ -1396,11 +1396,12 @@ int reg_engine_run(const EvalCall& call, const void* d_prog, const RegProgram& P
     const void* fn = P.hdr.block == 64 ? (const void*)k_reg_eval<64>
                    : P.hdr.block == 128 ? (const void*)k_reg_eval<128>
                    : P.hdr.block == 256 ? (const void*)k_reg_eval<256>
-                                        : (const void*)k_reg_eval<512>;
+                   : P.hdr.block == 512 ? (const void*)k_reg_eval<512>
+                                        : (const void*)k_reg_eval<1024>;
     VQA_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.lds_bytes));
     const int64_t groups = (call.E + S - 1) / S;
     // resident workgroups per CU: LDS, and the register budget of the launch bounds
-    const int by_regs = (P.hdr.block == 512 ? 2 : VQA_WAVES) * 4 / (P.hdr.block / 64);
+    const int by_regs = std::max(1, (P.hdr.block == 1024 ? 4 : P.hdr.block == 512 ? 2 : VQA_WAVES) * 4 / (P.hdr.block / 64));
     const int by_lds = (int)((160 * 1024) / std::max<size_t>(P.lds_bytes, 1));
     const int per_cu = std::max(1, std::min(8, std::min(by_regs, by_lds)));
     const int grid = (int)std::min<int64_t>(groups, (int64_t)256 * per_cu);
@@ -1408,7 +1409,8 @@ int reg_engine_run(const EvalCall& call, const void* d_prog, const RegProgram& P
     case 64: hipLaunchKernelGGL(k_reg_eval<64>, dim3(grid), dim3(64), P.lds_bytes, call.stream, a); break;
     case 128: hipLaunchKernelGGL(k_reg_eval<128>, dim3(grid), dim3(128), P.lds_bytes, call.stream, a); break;
     case 256: hipLaunchKernelGGL(k_reg_eval<256>, dim3(grid), dim3(256), P.lds_bytes, call.stream, a); break;
-    default: hipLaunchKernelGGL(k_reg_eval<512>, dim3(grid), dim3(512), P.lds_bytes, call.stream, a); break;
+    case 512: hipLaunchKernelGGL(k_reg_eval<512>, dim3(grid), dim3(512), P.lds_bytes, call.stream, a); break;
+    default: hipLaunchKernelGGL(k_reg_eval<1024>, dim3(grid), dim3(1024), P.lds_bytes, call.stream, a); break;
     }
     VQA_HIP(hipGetLastError());
     return VQA_OK;
@@ -1479,13 +1481,15 @@ int reg_engine_sweep(const EvalCall& call, const void* d_prog, const RegProgram&
     const void* fn = P.hdr.block == 64 ? (const void*)k_reg_psr<64>
                    : P.hdr.block == 128 ? (const void*)k_reg_psr<128>
                    : P.hdr.block == 256 ? (const void*)k_reg_psr<256>
-                                        : (const void*)k_reg_psr<512>;
+                   : P.hdr.block == 512 ? (const void*)k_reg_psr<512>
+                                        : (const void*)k_reg_psr<1024>;
     VQA_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.lds_bytes_psr));
     switch (P.hdr.block) {
     case 64: hipLaunchKernelGGL(k_reg_psr<64>, dim3(grid), dim3(64), P.lds_bytes_psr, call.stream, a); break;
     case 128: hipLaunchKernelGGL(k_reg_psr<128>, dim3(grid), dim3(128), P.lds_bytes_psr, call.stream, a); break;
     case 256: hipLaunchKernelGGL(k_reg_psr<256>, dim3(grid), dim3(256), P.lds_bytes_psr, call.stream, a); break;
-    default: hipLaunchKernelGGL(k_reg_psr<512>, dim3(grid), dim3(512), P.lds_bytes_psr, call.stream, a); break;
+    case 512: hipLaunchKernelGGL(k_reg_psr<512>, dim3(grid), dim3(512), P.lds_bytes_psr, call.stream, a); break;
+    default: hipLaunchKernelGGL(k_reg_psr<1024>, dim3(grid), dim3(1024), P.lds_bytes_psr, call.stream, a); break;
     }
     VQA_HIP(hipGetLastError());
     if (n_dead) {

@@ -210,7 +210,7 @@ bool reg_compile(int n, int n_theta, const std::vector<vqa_op>& gate_list, RegPr
     const int R = kRegBits;
     if (n < R) { *why = "fewer qubits than register bits"; return false; }
     const int T = n - R;
-    if (T > kMaxThreadBits || T > 9) { *why = "too many qubits for one workgroup"; return false; }
+    if (T > kMaxThreadBits) { *why = "too many qubits for one workgroup"; return false; }
     const int L = std::min(T, 6), W = T - L;
     RegProgram& P = *out;
     P = RegProgram();
@@ -544,10 +544,11 @@ bool reg_compile(int n, int n_theta, const std::vector<vqa_op>& gate_list, RegPr
 
     const size_t tab1 = ((size_t)H.n_uent + H.n_d1 + H.n_d2) * 16;
     const size_t xbuf = H.has_xpose ? ((size_t)8 << n) : 0;  // half of the state at a time
-    const size_t fixed = 64 * sizeof(double) + (((size_t)H.n_sign * H.block * 2 + 15) & ~(size_t)15);
+    const size_t fixed = 128 * sizeof(double) + (((size_t)H.n_sign * H.block * 2 + 15) & ~(size_t)15);
     P.lds_bytes = (size_t)H.S * tab1 + xbuf + fixed;
     P.lds_bytes_psr = tab1 + xbuf + fixed + 16 * 16 + 80 * sizeof(double);  // + run record, unshifted values
-    if (P.lds_bytes > 160 * 1024) { *why = "per-evaluation tables do not fit LDS"; return false; }
+    // (64 bytes of margin for the kernels' few statically allocated words)
+    if (std::max(P.lds_bytes, P.lds_bytes_psr) + 64 > 160 * 1024) { *why = "per-evaluation tables do not fit LDS"; return false; }
 
     // ---- device blob ----
     P.blob.assign(sizeof(RegHeader), 0);

@@ -232,7 +232,7 @@ static int run_call(EvalCall& call, DeviceCtx* ctx) {
         // gate-by-gate LDS engine (13 qubits: to the streaming engine); same results
         bool z_only = call.n_marg_bits <= 6;
         for (int t = 0; t < call.obs.n_terms; ++t) z_only &= call.obs.x[t] == 0;
-        if (!z_only) engine = call.c->n_qubits <= 12 ? 1 : 3;
+        if (!z_only) engine = call.c->n_qubits <= 12 ? 1 : 3;   // (13, 14 qubits: the streaming engine)
         // automatic choice at 4 and 5 qubits (a state is a thread or two): sweeps stay here (their
         // groups share the prepared tables: 2x to 6x the LDS engine), explicit lists, where every
         // instance prepares all its fused 2x2s, go to the LDS engine (2x to 4x this one)
@@ -354,7 +354,7 @@ int vqa_circuit_create(int n_qubits, const vqa_op* ops, int n_ops, int n_theta, 
     }
     int engine = g_engine;
     std::shared_ptr<RegProgram> reg;
-    if ((engine == 0 && n_qubits >= kRegBits && n_qubits <= 13) || engine == 2) {
+    if ((engine == 0 && n_qubits >= kRegBits && n_qubits <= kRegBits + kMaxThreadBits) || engine == 2) {
         reg = std::make_shared<RegProgram>();
         std::string why;
         std::vector<vqa_op> v(ops, ops + n_ops);
@@ -368,8 +368,8 @@ int vqa_circuit_create(int n_qubits, const vqa_op* ops, int n_ops, int n_theta, 
     // automatic, when the register engine does not take the circuit: the LDS engine below the
     // streaming engine's tiles (at 13 qubits its sweeps are 12x the LDS engine's)
     if (engine == 0) engine = n_qubits <= 12 ? 1 : 3;
-    if ((engine == 1 || engine == 2) && n_qubits > lds_engine_max_qubits())
-        VQA_FAIL(VQA_EUNSUPPORTED, "the workgroup-resident engines hold at most %d qubits", lds_engine_max_qubits());
+    if (engine == 1 && n_qubits > lds_engine_max_qubits())
+        VQA_FAIL(VQA_EUNSUPPORTED, "the LDS engine holds at most %d qubits", lds_engine_max_qubits());
     vqa_circuit* c = new (std::nothrow) vqa_circuit();
     if (!c) VQA_FAIL(VQA_ENOMEM, "out of host memory");
     c->reg = reg;
