@@ -807,8 +807,7 @@ struct ZBatch {
     uint64_t z[kZBatch];
     double coef[kZBatch];
     int col[kZBatch];  // output column (observable) each term adds to
-    int marg_bits;  // > 0: bins m0 .. m0+nz-1 of the low-bit marginal instead of Z-strings
-    int m0;
+    int bin[kZBatch];  // < 0: Z-string z (a sign); >= 0: the indicator of (index & z) == bin (a marginal bin)
 };
 
 __device__ __forceinline__ double block_sum(double v, double* red) {
@@ -831,15 +830,14 @@ __global__ __launch_bounds__(kT) void k_zpart(const double2* st, int n, ZBatch z
     double acc[kZBatch];
 #pragma unroll
     for (int t = 0; t < kZBatch; ++t) acc[t] = 0.0;
-    const int M1 = (1 << zb.marg_bits) - 1;
     for (int64_t k = (int64_t)blockIdx.x * kT + threadIdx.x; k < D; k += (int64_t)nb * kT) {
         const double2 v = s[k];
         const double pr = v.x * v.x + v.y * v.y;
 #pragma unroll
         for (int t = 0; t < kZBatch; ++t) {
             if (t < zb.nz) {
-                if (zb.marg_bits > 0)
-                    acc[t] += ((int)(k & M1) == zb.m0 + t) ? pr : 0.0;
+                if (zb.bin[t] >= 0)
+                    acc[t] += (((uint64_t)k & zb.z[t]) == (uint64_t)zb.bin[t]) ? pr : 0.0;
                 else
                     acc[t] += (__popcll((uint64_t)k & zb.z[t]) & 1) ? -pr : pr;
             }
@@ -888,10 +886,11 @@ __global__ __launch_bounds__(kT) void k_out_init(double* out, int64_t e_base, in
 
 // stage 2: marginal bins (spread): out[(e_base + ci) * stride + col0 + t] = sum_blk partial;
 // expectation terms: out[(e_base + ci) * stride + column of t] += coef_t * sum_blk partial
+// (entries t0 .. t0 + nz - 1 of the batch)
 __global__ __launch_bounds__(kT) void k_finish(const double* partial, int nb, int nz, ZBatch zb,
                                                int use_coef, double xcoef, double* out,
                                                int64_t e_base, int stride, int col0, int spread,
-                                               EvalSpec spec) {
+                                               EvalSpec spec, int t0) {
     __shared__ double red[4];
     const int ci = blockIdx.x;
     bool valid;
@@ -903,13 +902,13 @@ __global__ __launch_bounds__(kT) void k_finish(const double* partial, int nb, in
     const double nanv = __longlong_as_double(0x7ff8000000000000LL);
     for (int t = 0; t < nz; ++t) {
         double v = 0.0;
-        for (int b = threadIdx.x; b < nb; b += kT) v += partial[((int64_t)ci * nb + b) * kZBatch + t];
+        for (int b = threadIdx.x; b < nb; b += kT) v += partial[((int64_t)ci * nb + b) * kZBatch + t0 + t];
         const double r = block_sum(v, red);
         if (threadIdx.x == 0) {
             if (spread) {  // one output column per t (marginal bins)
                 out[(e_base + ci) * stride + col0 + t] = valid ? r : nanv;
             } else {       // NaN from k_out_init stays NaN
-                out[(e_base + ci) * stride + (use_coef ? zb.col[t] : col0)] += (use_coef ? zb.coef[t] : xcoef) * r;
+                out[(e_base + ci) * stride + (use_coef ? zb.col[t0 + t] : col0)] += (use_coef ? zb.coef[t0 + t] : xcoef) * r;
             }
         }
     }
@@ -966,7 +965,6 @@ __global__ __launch_bounds__(kT) void k_zpart2(const double2* f, const double2* 
     double acc[kZBatch], acx[kZBatch];
 #pragma unroll
     for (int t = 0; t < kZBatch; ++t) { acc[t] = 0.0; acx[t] = 0.0; }
-    const int M1 = (1 << zb.marg_bits) - 1;
     for (int64_t k = (int64_t)blockIdx.x * kT + threadIdx.x; k < D; k += (int64_t)nb * kT) {
         const double2 v = s[k], u = f[k];
         const double pr = v.x * v.x + v.y * v.y;
@@ -974,8 +972,8 @@ __global__ __launch_bounds__(kT) void k_zpart2(const double2* f, const double2* 
 #pragma unroll
         for (int t = 0; t < kZBatch; ++t) {
             if (t < zb.nz) {
-                if (zb.marg_bits > 0) {
-                    const bool in = (int)(k & M1) == zb.m0 + t;
+                if (zb.bin[t] >= 0) {
+                    const bool in = ((uint64_t)k & zb.z[t]) == (uint64_t)zb.bin[t];
                     acc[t] += in ? pr : 0.0;
                     acx[t] += in ? cr : 0.0;
                 } else {
@@ -1047,7 +1045,7 @@ __global__ __launch_bounds__(kT) void k_out_init2(double* out, int64_t row0, con
 __global__ __launch_bounds__(kT) void k_finish2(const double* partial, int nb, int nz, ZBatch zb, int use_coef,
                                                 double xcoef, double* out, int64_t row0, const int32_t* ord,
                                                 const double* ord_coef, double shift, int stride, int col0,
-                                                int spread) {
+                                                int spread, int t0) {
     __shared__ double red[4];
     const int ci = blockIdx.x;
     double sn, c;
@@ -1056,7 +1054,7 @@ __global__ __launch_bounds__(kT) void k_finish2(const double* partial, int nb, i
     for (int t = 0; t < nz; ++t) {
         double va = 0.0, vx = 0.0;
         for (int b = threadIdx.x; b < nb; b += kT) {
-            const double* q = &partial[(((int64_t)ci * nb + b) * kZBatch + t) * 2];
+            const double* q = &partial[(((int64_t)ci * nb + b) * kZBatch + t0 + t) * 2];
             va += q[0];
             vx += q[1];
         }
@@ -1068,8 +1066,8 @@ __global__ __launch_bounds__(kT) void k_finish2(const double* partial, int nb, i
                 out[rp * stride + col0 + t] = base + sn * sn * a + 2.0 * c * sn * x;
                 out[rm * stride + col0 + t] = base + sn * sn * a - 2.0 * c * sn * x;
             } else {
-                const double cf = use_coef ? zb.coef[t] : xcoef;
-                const int col = use_coef ? zb.col[t] : col0;
+                const double cf = use_coef ? zb.coef[t0 + t] : xcoef;
+                const int col = use_coef ? zb.col[t0 + t] : col0;
                 out[rp * stride + col] += cf * (sn * sn * a + 2.0 * c * sn * x);
                 out[rm * stride + col] += cf * (sn * sn * a - 2.0 * c * sn * x);
             }
@@ -1328,23 +1326,46 @@ int measure_states(const EvalCall& call, double2* st, int C, int64_t e0, int nb,
         else
             hipLaunchKernelGGL(k_out_init, dim3(g), dim3(kT), 0, call.stream, call.d_out_expect, e0, C, n_obs, call.spec);
     }
-    // Z-strings of all observables, kZBatch at a time; `f` = the unshifted state the pairs are taken with
-    auto zflush = [&](ZBatch& zb, const double2* states, const double2* f) {
+    // Z-strings of all observables, kZBatch at a time; `f` = the unshifted state the pairs are taken with.
+    // The bins of the low-bit marginal ride in the same pass over the states when they fit behind
+    // the last Z-strings (entries nzs .. nz - 1 of the batch).
+    const int M = call.n_marg_bits > 0 ? 1 << call.n_marg_bits : 0;
+    bool marg_done = M == 0;
+    auto zflush = [&](ZBatch& zb, const double2* states, const double2* f, bool last) {
+        const int nzs = zb.nz;
+        int nbins = 0;
+        if (last && !marg_done && nzs + M <= kZBatch) {
+            for (int m = 0; m < M; ++m) {
+                zb.z[nzs + m] = (uint64_t)(M - 1);
+                zb.bin[nzs + m] = m;
+                zb.coef[nzs + m] = 0.0;
+                zb.col[nzs + m] = 0;
+            }
+            nbins = M;
+            zb.nz = nzs + M;
+            marg_done = true;
+        }
         if (zb.nz == 0) return;
         if (pair) {
             hipLaunchKernelGGL(k_zpart2, dim3(nb, C), dim3(kT), 0, call.stream, f, states, n, zb, partial);
-            hipLaunchKernelGGL(k_finish2, dim3(C), dim3(kT), 0, call.stream, partial, nb, zb.nz, zb, 1, 0.0,
-                               call.d_out_expect, pair->row0, pair->ord, pair->ord_coef, pair->shift, n_obs, 0, 0);
+            if (nzs)
+                hipLaunchKernelGGL(k_finish2, dim3(C), dim3(kT), 0, call.stream, partial, nb, nzs, zb, 1, 0.0,
+                                   call.d_out_expect, pair->row0, pair->ord, pair->ord_coef, pair->shift, n_obs, 0, 0, 0);
+            if (nbins)
+                hipLaunchKernelGGL(k_finish2, dim3(C), dim3(kT), 0, call.stream, partial, nb, nbins, zb, 1, 0.0,
+                                   call.d_out_marginal, pair->row0, pair->ord, pair->ord_coef, pair->shift, M, 0, 1, nzs);
         } else {
             hipLaunchKernelGGL(k_zpart, dim3(nb, C), dim3(kT), 0, call.stream, states, n, zb, partial);
-            hipLaunchKernelGGL(k_finish, dim3(C), dim3(kT), 0, call.stream, partial, nb, zb.nz, zb, 1, 0.0,
-                               call.d_out_expect, e0, n_obs, 0, 0, call.spec);
+            if (nzs)
+                hipLaunchKernelGGL(k_finish, dim3(C), dim3(kT), 0, call.stream, partial, nb, nzs, zb, 1, 0.0,
+                                   call.d_out_expect, e0, n_obs, 0, 0, call.spec, 0);
+            if (nbins)
+                hipLaunchKernelGGL(k_finish, dim3(C), dim3(kT), 0, call.stream, partial, nb, nbins, zb, 0, 0.0,
+                                   call.d_out_marginal, e0, M, 0, 1, call.spec, nzs);
         }
         zb.nz = 0;
     };
     ZBatch zb;
-    zb.marg_bits = 0;
-    zb.m0 = 0;
     zb.nz = 0;
     for (int o = 0; o < n_obs; ++o) {
         for (int t = call.obs.off[o]; t < call.obs.off[o + 1]; ++t) {
@@ -1352,10 +1373,11 @@ int measure_states(const EvalCall& call, double2* st, int C, int64_t e0, int nb,
             zb.z[zb.nz] = call.obs.z[t];
             zb.coef[zb.nz] = call.obs.coef[t];
             zb.col[zb.nz] = o;
-            if (++zb.nz == kZBatch) zflush(zb, st, pair ? pair->f : nullptr);
+            zb.bin[zb.nz] = -1;
+            if (++zb.nz == kZBatch) zflush(zb, st, pair ? pair->f : nullptr, false);
         }
     }
-    zflush(zb, st, pair ? pair->f : nullptr);
+    zflush(zb, st, pair ? pair->f : nullptr, true);
     // X/Y strings one at a time, except the pure-X ones when the Hadamard layer is in use
     for (int o = 0; o < n_obs; ++o) {
         for (int t = call.obs.off[o]; t < call.obs.off[o + 1]; ++t) {
@@ -1365,30 +1387,33 @@ int measure_states(const EvalCall& call, double2* st, int C, int64_t e0, int nb,
                                    call.obs.z[t], call.obs.x[t], partial);
                 hipLaunchKernelGGL(k_finish2, dim3(C), dim3(kT), 0, call.stream, partial, nb, 1, zb, 0,
                                    call.obs.coef[t], call.d_out_expect, pair->row0, pair->ord,
-                                   pair->ord_coef, pair->shift, n_obs, o, 0);
+                                   pair->ord_coef, pair->shift, n_obs, o, 0, 0);
             } else {
                 hipLaunchKernelGGL(k_xpart, dim3(nb, C), dim3(kT), 0, call.stream, st, n,
                                    call.obs.z[t], call.obs.x[t], partial);
                 hipLaunchKernelGGL(k_finish, dim3(C), dim3(kT), 0, call.stream, partial, nb,
-                                   1, zb, 0, call.obs.coef[t], call.d_out_expect, e0, n_obs, o, 0, call.spec);
+                                   1, zb, 0, call.obs.coef[t], call.d_out_expect, e0, n_obs, o, 0, call.spec, 0);
             }
         }
     }
-    if (call.n_marg_bits > 0) {
-        const int M = 1 << call.n_marg_bits;
+    if (!marg_done) {
         for (int m0 = 0; m0 < M; m0 += kZBatch) {
             ZBatch mb;
-            mb.marg_bits = call.n_marg_bits;
-            mb.m0 = m0;
             mb.nz = std::min(kZBatch, M - m0);
+            for (int m = 0; m < mb.nz; ++m) {
+                mb.z[m] = (uint64_t)(M - 1);
+                mb.bin[m] = m0 + m;
+                mb.coef[m] = 0.0;
+                mb.col[m] = 0;
+            }
             if (pair) {
                 hipLaunchKernelGGL(k_zpart2, dim3(nb, C), dim3(kT), 0, call.stream, pair->f, st, n, mb, partial);
                 hipLaunchKernelGGL(k_finish2, dim3(C), dim3(kT), 0, call.stream, partial, nb, mb.nz, mb, 1, 0.0,
-                                   call.d_out_marginal, pair->row0, pair->ord, pair->ord_coef, pair->shift, M, m0, 1);
+                                   call.d_out_marginal, pair->row0, pair->ord, pair->ord_coef, pair->shift, M, m0, 1, 0);
             } else {
                 hipLaunchKernelGGL(k_zpart, dim3(nb, C), dim3(kT), 0, call.stream, st, n, mb, partial);
                 hipLaunchKernelGGL(k_finish, dim3(C), dim3(kT), 0, call.stream, partial, nb, mb.nz, mb, 0, 0.0,
-                                   call.d_out_marginal, e0, M, m0, 1, call.spec);
+                                   call.d_out_marginal, e0, M, m0, 1, call.spec, 0);
             }
         }
     }
@@ -1409,10 +1434,11 @@ int measure_states(const EvalCall& call, double2* st, int C, int64_t e0, int nb,
                 zb.z[zb.nz] = call.obs.x[t];
                 zb.coef[zb.nz] = call.obs.coef[t];
                 zb.col[zb.nz] = o;
-                if (++zb.nz == kZBatch) zflush(zb, hs, pair ? pair->fh : nullptr);
+                zb.bin[zb.nz] = -1;
+                if (++zb.nz == kZBatch) zflush(zb, hs, pair ? pair->fh : nullptr, false);
             }
         }
-        zflush(zb, hs, pair ? pair->fh : nullptr);
+        zflush(zb, hs, pair ? pair->fh : nullptr, false);
     }
     VQA_HIP(hipGetLastError());
     return VQA_OK;
