@@ -822,19 +822,21 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
 }
 
 // stage 1: partial[(ci * nb + blk) * kZBatch + t] = sum over the block's slice
+// (NZ = accumulators kept per thread: batches of up to 8 entries run with a quarter of the registers)
+template <int NZ>
 __global__ __launch_bounds__(kT) void k_zpart(const double2* st, int n, ZBatch zb, double* partial) {
     __shared__ double red[4];
     const int64_t D = (int64_t)1 << n;
     const int ci = blockIdx.y, nb = gridDim.x;
     const double2* s = st + ((int64_t)ci << n);
-    double acc[kZBatch];
+    double acc[NZ];
 #pragma unroll
-    for (int t = 0; t < kZBatch; ++t) acc[t] = 0.0;
+    for (int t = 0; t < NZ; ++t) acc[t] = 0.0;
     for (int64_t k = (int64_t)blockIdx.x * kT + threadIdx.x; k < D; k += (int64_t)nb * kT) {
         const double2 v = s[k];
         const double pr = v.x * v.x + v.y * v.y;
 #pragma unroll
-        for (int t = 0; t < kZBatch; ++t) {
+        for (int t = 0; t < NZ; ++t) {
             if (t < zb.nz) {
                 if (zb.bin[t] >= 0)
                     acc[t] += (((uint64_t)k & zb.z[t]) == (uint64_t)zb.bin[t]) ? pr : 0.0;
@@ -844,7 +846,7 @@ __global__ __launch_bounds__(kT) void k_zpart(const double2* st, int n, ZBatch z
         }
     }
 #pragma unroll
-    for (int t = 0; t < kZBatch; ++t) {
+    for (int t = 0; t < NZ; ++t) {
         if (t < zb.nz) {
             const double r = block_sum(acc[t], red);
             if (threadIdx.x == 0) partial[((int64_t)ci * nb + blockIdx.x) * kZBatch + t] = r;
@@ -956,21 +958,22 @@ __global__ __launch_bounds__(kT) void k_spawn(double2* dst, const double2* src, 
 
 // stage 1 for state pairs (psi = f, phi = slot ci): per Z-string (or marginal bin) the sums
 // of sign |phi|^2 and sign Re(conj(psi) phi); partial[((ci * nb + blk) * kZBatch + t) * 2 + {0, 1}]
+template <int NZ>
 __global__ __launch_bounds__(kT) void k_zpart2(const double2* f, const double2* st, int n, ZBatch zb,
                                                double* partial) {
     __shared__ double red[4];
     const int64_t D = (int64_t)1 << n;
     const int ci = blockIdx.y, nb = gridDim.x;
     const double2* s = st + ((int64_t)ci << n);
-    double acc[kZBatch], acx[kZBatch];
+    double acc[NZ], acx[NZ];
 #pragma unroll
-    for (int t = 0; t < kZBatch; ++t) { acc[t] = 0.0; acx[t] = 0.0; }
+    for (int t = 0; t < NZ; ++t) { acc[t] = 0.0; acx[t] = 0.0; }
     for (int64_t k = (int64_t)blockIdx.x * kT + threadIdx.x; k < D; k += (int64_t)nb * kT) {
         const double2 v = s[k], u = f[k];
         const double pr = v.x * v.x + v.y * v.y;
         const double cr = u.x * v.x + u.y * v.y;
 #pragma unroll
-        for (int t = 0; t < kZBatch; ++t) {
+        for (int t = 0; t < NZ; ++t) {
             if (t < zb.nz) {
                 if (zb.bin[t] >= 0) {
                     const bool in = ((uint64_t)k & zb.z[t]) == (uint64_t)zb.bin[t];
@@ -985,7 +988,7 @@ __global__ __launch_bounds__(kT) void k_zpart2(const double2* f, const double2* 
         }
     }
 #pragma unroll
-    for (int t = 0; t < kZBatch; ++t) {
+    for (int t = 0; t < NZ; ++t) {
         if (t < zb.nz) {
             const double r = block_sum(acc[t], red);
             const double rx = block_sum(acx[t], red);
@@ -1347,7 +1350,8 @@ int measure_states(const EvalCall& call, double2* st, int C, int64_t e0, int nb,
         }
         if (zb.nz == 0) return;
         if (pair) {
-            hipLaunchKernelGGL(k_zpart2, dim3(nb, C), dim3(kT), 0, call.stream, f, states, n, zb, partial);
+            if (zb.nz <= 8) hipLaunchKernelGGL(k_zpart2<8>, dim3(nb, C), dim3(kT), 0, call.stream, f, states, n, zb, partial);
+            else hipLaunchKernelGGL(k_zpart2<kZBatch>, dim3(nb, C), dim3(kT), 0, call.stream, f, states, n, zb, partial);
             if (nzs)
                 hipLaunchKernelGGL(k_finish2, dim3(C), dim3(kT), 0, call.stream, partial, nb, nzs, zb, 1, 0.0,
                                    call.d_out_expect, pair->row0, pair->ord, pair->ord_coef, pair->shift, n_obs, 0, 0, 0);
@@ -1355,7 +1359,8 @@ int measure_states(const EvalCall& call, double2* st, int C, int64_t e0, int nb,
                 hipLaunchKernelGGL(k_finish2, dim3(C), dim3(kT), 0, call.stream, partial, nb, nbins, zb, 1, 0.0,
                                    call.d_out_marginal, pair->row0, pair->ord, pair->ord_coef, pair->shift, M, 0, 1, nzs);
         } else {
-            hipLaunchKernelGGL(k_zpart, dim3(nb, C), dim3(kT), 0, call.stream, states, n, zb, partial);
+            if (zb.nz <= 8) hipLaunchKernelGGL(k_zpart<8>, dim3(nb, C), dim3(kT), 0, call.stream, states, n, zb, partial);
+            else hipLaunchKernelGGL(k_zpart<kZBatch>, dim3(nb, C), dim3(kT), 0, call.stream, states, n, zb, partial);
             if (nzs)
                 hipLaunchKernelGGL(k_finish, dim3(C), dim3(kT), 0, call.stream, partial, nb, nzs, zb, 1, 0.0,
                                    call.d_out_expect, e0, n_obs, 0, 0, call.spec, 0);
@@ -1407,11 +1412,13 @@ int measure_states(const EvalCall& call, double2* st, int C, int64_t e0, int nb,
                 mb.col[m] = 0;
             }
             if (pair) {
-                hipLaunchKernelGGL(k_zpart2, dim3(nb, C), dim3(kT), 0, call.stream, pair->f, st, n, mb, partial);
+                if (mb.nz <= 8) hipLaunchKernelGGL(k_zpart2<8>, dim3(nb, C), dim3(kT), 0, call.stream, pair->f, st, n, mb, partial);
+                else hipLaunchKernelGGL(k_zpart2<kZBatch>, dim3(nb, C), dim3(kT), 0, call.stream, pair->f, st, n, mb, partial);
                 hipLaunchKernelGGL(k_finish2, dim3(C), dim3(kT), 0, call.stream, partial, nb, mb.nz, mb, 1, 0.0,
                                    call.d_out_marginal, pair->row0, pair->ord, pair->ord_coef, pair->shift, M, m0, 1, 0);
             } else {
-                hipLaunchKernelGGL(k_zpart, dim3(nb, C), dim3(kT), 0, call.stream, st, n, mb, partial);
+                if (mb.nz <= 8) hipLaunchKernelGGL(k_zpart<8>, dim3(nb, C), dim3(kT), 0, call.stream, st, n, mb, partial);
+                else hipLaunchKernelGGL(k_zpart<kZBatch>, dim3(nb, C), dim3(kT), 0, call.stream, st, n, mb, partial);
                 hipLaunchKernelGGL(k_finish, dim3(C), dim3(kT), 0, call.stream, partial, nb, mb.nz, mb, 0, 0.0,
                                    call.d_out_marginal, e0, M, m0, 1, call.spec, 0);
             }
