@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--engine", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short single-GPU measurements of the 6- and 20-qubit configurations")
     ap.add_argument("--backend", default="nccl", help="process-group backend (gloo: rehearsals of the N > 1 path)")
     ap.add_argument("--force-dist", action="store_true",
                     help="create the process group even for one rank (exercises the RCCL calls on a one-GPU box)")
@@ -225,6 +227,10 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(circ, theta, ia, P, args.cpu_seconds)
+        if not args.no_other_configs and world == 1 and args.workload == "hea12_d10_b65536" and not args.batch:
+            d_out = d_in = None   # (the 3.3 GB of headline outputs: the 20-qubit sweep wants the memory)
+            torch.cuda.empty_cache()
+            res["other_configs"] = other_configs(local_rank)
         print(json.dumps(res), flush=True)
     if use_dist:
         dist.destroy_process_group()
@@ -302,6 +308,36 @@ def roofline(bytes_alg, flops_alg, evals, kern_ms, measured):
         if "fp64_fma_tflops" in measured:
             r["frac_of_measured_peak"] = tflops / measured["fp64_fma_tflops"]
     return r
+
+
+def other_configs(device):
+    """Full parameter-shift sweeps of the two other QNN configurations that fit one GPU in seconds,
+    measured after the timed region (one GPU, <Z0>, inputs resident): not the headline value."""
+    import torch
+
+    from vqa_amd import LearningCircuit, create_ibm_HEA_ansatz, z_observable
+
+    out = {}
+    for name, n, d, B, n_feat, reps in (("sin(x) regressor: 6 qubits, depth 5, batch 4096", 6, 5, 4096, 1, 5),
+                                        ("20-qubit QNN: depth 8 (HBM engine), 4 of the batch's 1024 samples", 20, 8, 4, 20, 1)):
+        rng = np.random.default_rng(1)
+        c = create_ibm_HEA_ansatz(n, d, seed=0, circuit_cls=lambda nq: LearningCircuit(nq, device=device))
+        x = c.upload_inputs(rng.uniform(0.0, np.pi, (B, n_feat)))
+        th = torch.from_numpy(rng.uniform(0.0, 2 * np.pi, c.n_theta)).to(x.device)
+        obs = [z_observable(n, 0)]
+        c.psr_full(th, x, n_sel=min(B, 2), obs_list=obs)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            c.psr_full(th, x, n_sel=B, obs_list=obs)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        K = 2 * c.n_theta + 1
+        out[name] = {"gradients_per_sec": B / dt, "circuit_evals_per_sec": B * K / dt, "n_params": c.n_theta,
+                     "ms_per_call": 1e3 * dt}
+        del c, x
+        torch.cuda.empty_cache()
+    return out
 
 
 def cpu_baseline(circ, theta, ia, P, seconds):
