@@ -144,6 +144,29 @@ def test_device_statistics_sampled_gradient():
     assert np.all(gd.std(axis=0) < 1.8 * sd) and np.all(gd.std(axis=0) > sd / 1.8)
 
 
+@pytest.mark.parametrize("unbias,partial", [(True, True), (False, False), (True, False)])
+def test_classifier_device_statistics_gradient(unbias, partial):
+    """Classifier MSE gradient with the class counts drawn by the device sampler: the host path's
+    counters and shot totals, an unbiased estimate of the infinite-shot gradient (mean of repeated
+    draws against the mean of the host path's draws), and the host path's scatter."""
+    (g, p), (o, _) = pair(create_ibm_HEA_ansatz, 5, 1, myQNN_classifier, n_train=24, class_unbias=unbias)
+    g.device_statistics = True
+    shots = np.full(g.n_params, 300)
+    N = len(g.x_train)
+    np.random.seed(5)
+    g.MSE_grad_eval(p, shots, mini_batch_size=N, partial_MSE=partial)
+    np.random.seed(5)
+    o.MSE_grad_eval(p, shots, mini_batch_size=N, partial_MSE=partial)
+    assert (g.shots_counter[0], g.call_counter[0], g.circuit_counter[0]) == \
+           (o.shots_counter[0], o.call_counter[0], o.circuit_counter[0])
+    R = 80
+    gd = np.array([g.MSE_grad_eval(p, shots, mini_batch_size=N, partial_MSE=partial) for _ in range(R)])
+    gh = np.array([o.MSE_grad_eval(p, shots, mini_batch_size=N, partial_MSE=partial) for _ in range(R)])
+    sd = gh.std(axis=0) + 1e-12
+    assert np.max(np.abs(gd.mean(axis=0) - gh.mean(axis=0)) / sd) < 6 * np.sqrt(2.0 / R)
+    assert np.all(gd.std(axis=0) < 1.8 * sd) and np.all(gd.std(axis=0) > sd / 1.8)
+
+
 @pytest.mark.parametrize("second_order,max_n0", [(True, True), (False, False)])
 def test_device_ieval_equals_host_algebra(second_order, max_n0):
     """MSE_iEval evaluated on the GPU (all parameters at once, fallbacks included) against the

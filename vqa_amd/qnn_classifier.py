@@ -285,6 +285,10 @@ class myQNN_classifier(myQNN_base):
         self.partial_MSE = partial_MSE
         grad = np.zeros_like(params)
         wt_dist, eval_ind, y_eval, y_1hot = self._setup(mini_batch_size, option_weight)
+        if getattr(self, "device_statistics", False):
+            g = self._grad_on_device(params, n_shots_list, wt_dist, eval_ind, y_eval, y_1hot, partial_MSE)
+            if g is not None:
+                return g
         M = self._psr_marginals(params, eval_ind)
         n0 = np.floor(np.max(n_shots_list) * wt_dist).astype(int)
         c0 = self._draw_class_counts(M[:, 0], n0)
@@ -301,6 +305,54 @@ class myQNN_classifier(myQNN_base):
             else:
                 grad[i] = np.mean(np.sum(err * (cp / n_i[:, None] - cm / n_i[:, None]), axis=1))
         return grad
+
+    def _grad_on_device(self, params, n_shots_list, wt_dist, eval_ind, y_eval, y_1hot, partial_MSE):
+        """MSE_grad_eval with the class counts drawn where the marginals are: one multinomial per
+        (sample, shift) from the library's device sampler (myQNNs_classifier.py:607-622 for all
+        2P+1 instances of every sample at once), outcome 3 re-dealt by a second multinomial when
+        class_unbias, products and batch means on the GPU.  Same estimators, counters and shot
+        totals as the host path; the random stream is the sampler's, seeded from NumPy's.  None when
+        the circuit does not compute on a GPU."""
+        theta = np.asarray(params[:self.n_c_params], dtype=np.float64)
+        _, M = self.circuit.psr_full(theta, self._handle("train"), sel=np.asarray(eval_ind, np.int32), obs_list=[],
+                                     n_marg_bits=2)
+        if not hasattr(M, "detach"):
+            return None
+        import torch
+
+        from .sampling import sample_counts
+
+        P = len(params)
+        B, K = int(M.shape[0]), int(M.shape[1])
+        n_all = np.floor(np.asarray(n_shots_list, dtype=float)[:P, None] * wt_dist[None, :])    # [P, B]
+        n0 = np.floor(np.max(n_shots_list) * wt_dist)
+        dev = M.device
+        n_inst = torch.empty((B, K), dtype=torch.int64, device=dev)
+        n_inst[:, 0] = torch.from_numpy(n0.astype(np.int64)).to(dev)
+        nt = torch.from_numpy(n_all.astype(np.int64).T.copy()).to(dev)
+        n_inst[:, 1::2] = nt
+        n_inst[:, 2::2] = nt
+        seed = int(np.random.randint(0, 2 ** 31 - 1))
+        k = sample_counts(M.reshape(B * K, 4).clamp(0.0, 1.0), n_inst.reshape(-1), seed)
+        if self.class_unbias:
+            third = torch.full((B * K, 3), 1.0 / 3.0, dtype=torch.float64, device=dev)
+            c = k[:, :3] + sample_counts(third, k[:, 3], seed, stream_id=1)
+        else:
+            c = torch.stack([k[:, 0] + k[:, 3], k[:, 1], k[:, 2]], dim=1)
+        q = c.reshape(B, K, 3).to(torch.float64) / n_inst.to(torch.float64)[:, :, None]            # class frequencies
+        if partial_MSE:
+            y = torch.from_numpy(np.asarray(y_eval, dtype=np.int64)).to(dev)
+            ps = q[torch.arange(B, device=dev), :, y]                                               # [B, K]
+            grad = ((ps[:, 0] - 1.0)[:, None] * (ps[:, 1::2] - ps[:, 2::2])).mean(0)
+        else:
+            err = q[:, 0, :] - torch.from_numpy(np.asarray(y_1hot, dtype=np.float64)).to(dev)
+            grad = (err[:, None, :] * (q[:, 1::2, :] - q[:, 2::2, :])).sum(-1).mean(0)
+        self.circuit_counter[0] += B * K
+        self.call_counter[0] += B * K
+        self.shots_counter[0] += int(n0.sum() + 2 * n_all.sum())
+        out = np.zeros_like(params)
+        out[:] = grad.cpu().numpy()
+        return out
 
     def _estimate_MSEgrad_mean_condVar(self, pp, pp2, varpp, pm, pm2, varpm, p0, p02, varp0, y_eval_1hot=None,
                                        second_order=False, partial_MSE=True):
