@@ -821,35 +821,49 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
     return r;
 }
 
-// stage 1: partial[(ci * nb + blk) * kZBatch + t] = sum over the block's slice
+// stage 1: partial[(ci * nb + blk) * kZBatch + t] = sum over the block's slice.
+// A block reads one contiguous slice of 2^n / nb amplitudes, a thread every kT-th of them: the
+// index bits below log2(kT) are fixed per thread and those from log2(slice) on per block, so an
+// entry whose mask avoids the bits in between has ONE sign (or bin test) per thread: it is applied
+// once, to the thread's plain sum, and only the other entries cost work per amplitude.
 // (NZ = accumulators kept per thread: batches of up to 8 entries run with a quarter of the registers)
 template <int NZ>
 __global__ __launch_bounds__(kT) void k_zpart(const double2* st, int n, ZBatch zb, double* partial) {
     __shared__ double red[4];
     const int64_t D = (int64_t)1 << n;
-    const int ci = blockIdx.y, nb = gridDim.x;
+    const int ci = blockIdx.x, blk = blockIdx.y, nb = gridDim.y;
     const double2* s = st + ((int64_t)ci << n);
     double acc[NZ];
 #pragma unroll
     for (int t = 0; t < NZ; ++t) acc[t] = 0.0;
-    for (int64_t k = (int64_t)blockIdx.x * kT + threadIdx.x; k < D; k += (int64_t)nb * kT) {
+    const int64_t L = D / nb;
+    const uint32_t vary = (uint32_t)((L - 1) & ~(int64_t)(kT - 1));
+    const uint32_t k0 = (uint32_t)(blk * L + threadIdx.x);
+    double tot = 0.0;
+    for (int64_t k = blk * L + threadIdx.x; k < (blk + 1) * L; k += kT) {
         const double2 v = s[k];
         const double pr = v.x * v.x + v.y * v.y;
+        const uint32_t k32 = (uint32_t)k;
+        tot += pr;
 #pragma unroll
         for (int t = 0; t < NZ; ++t) {
-            if (t < zb.nz) {
+            if (t < zb.nz && ((uint32_t)zb.z[t] & vary)) {
                 if (zb.bin[t] >= 0)
-                    acc[t] += (((uint64_t)k & zb.z[t]) == (uint64_t)zb.bin[t]) ? pr : 0.0;
+                    acc[t] += ((k32 & (uint32_t)zb.z[t]) == (uint32_t)zb.bin[t]) ? pr : 0.0;
                 else
-                    acc[t] += (__popcll((uint64_t)k & zb.z[t]) & 1) ? -pr : pr;
+                    acc[t] += (__popc(k32 & (uint32_t)zb.z[t]) & 1) ? -pr : pr;
             }
         }
     }
 #pragma unroll
     for (int t = 0; t < NZ; ++t) {
         if (t < zb.nz) {
+            if (!((uint32_t)zb.z[t] & vary)) {
+                if (zb.bin[t] >= 0) acc[t] = ((k0 & (uint32_t)zb.z[t]) == (uint32_t)zb.bin[t]) ? tot : 0.0;
+                else acc[t] = (__popc(k0 & (uint32_t)zb.z[t]) & 1) ? -tot : tot;
+            }
             const double r = block_sum(acc[t], red);
-            if (threadIdx.x == 0) partial[((int64_t)ci * nb + blockIdx.x) * kZBatch + t] = r;
+            if (threadIdx.x == 0) partial[((int64_t)ci * nb + blk) * kZBatch + t] = r;
         }
     }
 }
@@ -958,29 +972,38 @@ __global__ __launch_bounds__(kT) void k_spawn(double2* dst, const double2* src, 
 
 // stage 1 for state pairs (psi = f, phi = slot ci): per Z-string (or marginal bin) the sums
 // of sign |phi|^2 and sign Re(conj(psi) phi); partial[((ci * nb + blk) * kZBatch + t) * 2 + {0, 1}]
+// (slices and per-thread signs as in k_zpart; the slot is the fast grid index, so the blocks that
+// run side by side read the same slice of psi)
 template <int NZ>
 __global__ __launch_bounds__(kT) void k_zpart2(const double2* f, const double2* st, int n, ZBatch zb,
                                                double* partial) {
     __shared__ double red[4];
     const int64_t D = (int64_t)1 << n;
-    const int ci = blockIdx.y, nb = gridDim.x;
+    const int ci = blockIdx.x, blk = blockIdx.y, nb = gridDim.y;
     const double2* s = st + ((int64_t)ci << n);
     double acc[NZ], acx[NZ];
 #pragma unroll
     for (int t = 0; t < NZ; ++t) { acc[t] = 0.0; acx[t] = 0.0; }
-    for (int64_t k = (int64_t)blockIdx.x * kT + threadIdx.x; k < D; k += (int64_t)nb * kT) {
+    const int64_t L = D / nb;
+    const uint32_t vary = (uint32_t)((L - 1) & ~(int64_t)(kT - 1));
+    const uint32_t k0 = (uint32_t)(blk * L + threadIdx.x);
+    double tot = 0.0, totx = 0.0;
+    for (int64_t k = blk * L + threadIdx.x; k < (blk + 1) * L; k += kT) {
         const double2 v = s[k], u = f[k];
         const double pr = v.x * v.x + v.y * v.y;
         const double cr = u.x * v.x + u.y * v.y;
+        const uint32_t k32 = (uint32_t)k;
+        tot += pr;
+        totx += cr;
 #pragma unroll
         for (int t = 0; t < NZ; ++t) {
-            if (t < zb.nz) {
+            if (t < zb.nz && ((uint32_t)zb.z[t] & vary)) {
                 if (zb.bin[t] >= 0) {
-                    const bool in = ((uint64_t)k & zb.z[t]) == (uint64_t)zb.bin[t];
+                    const bool in = (k32 & (uint32_t)zb.z[t]) == (uint32_t)zb.bin[t];
                     acc[t] += in ? pr : 0.0;
                     acx[t] += in ? cr : 0.0;
                 } else {
-                    const bool neg = __popcll((uint64_t)k & zb.z[t]) & 1;
+                    const bool neg = __popc(k32 & (uint32_t)zb.z[t]) & 1;
                     acc[t] += neg ? -pr : pr;
                     acx[t] += neg ? -cr : cr;
                 }
@@ -990,10 +1013,21 @@ __global__ __launch_bounds__(kT) void k_zpart2(const double2* f, const double2* 
 #pragma unroll
     for (int t = 0; t < NZ; ++t) {
         if (t < zb.nz) {
+            if (!((uint32_t)zb.z[t] & vary)) {
+                if (zb.bin[t] >= 0) {
+                    const bool in = (k0 & (uint32_t)zb.z[t]) == (uint32_t)zb.bin[t];
+                    acc[t] = in ? tot : 0.0;
+                    acx[t] = in ? totx : 0.0;
+                } else {
+                    const bool neg = __popc(k0 & (uint32_t)zb.z[t]) & 1;
+                    acc[t] = neg ? -tot : tot;
+                    acx[t] = neg ? -totx : totx;
+                }
+            }
             const double r = block_sum(acc[t], red);
             const double rx = block_sum(acx[t], red);
             if (threadIdx.x == 0) {
-                double* o = &partial[(((int64_t)ci * nb + blockIdx.x) * kZBatch + t) * 2];
+                double* o = &partial[(((int64_t)ci * nb + blk) * kZBatch + t) * 2];
                 o[0] = r;
                 o[1] = rx;
             }
@@ -1350,8 +1384,8 @@ int measure_states(const EvalCall& call, double2* st, int C, int64_t e0, int nb,
         }
         if (zb.nz == 0) return;
         if (pair) {
-            if (zb.nz <= 8) hipLaunchKernelGGL(k_zpart2<8>, dim3(nb, C), dim3(kT), 0, call.stream, f, states, n, zb, partial);
-            else hipLaunchKernelGGL(k_zpart2<kZBatch>, dim3(nb, C), dim3(kT), 0, call.stream, f, states, n, zb, partial);
+            if (zb.nz <= 8) hipLaunchKernelGGL(k_zpart2<8>, dim3(C, nb), dim3(kT), 0, call.stream, f, states, n, zb, partial);
+            else hipLaunchKernelGGL(k_zpart2<kZBatch>, dim3(C, nb), dim3(kT), 0, call.stream, f, states, n, zb, partial);
             if (nzs)
                 hipLaunchKernelGGL(k_finish2, dim3(C), dim3(kT), 0, call.stream, partial, nb, nzs, zb, 1, 0.0,
                                    call.d_out_expect, pair->row0, pair->ord, pair->ord_coef, pair->shift, n_obs, 0, 0, 0);
@@ -1359,8 +1393,8 @@ int measure_states(const EvalCall& call, double2* st, int C, int64_t e0, int nb,
                 hipLaunchKernelGGL(k_finish2, dim3(C), dim3(kT), 0, call.stream, partial, nb, nbins, zb, 1, 0.0,
                                    call.d_out_marginal, pair->row0, pair->ord, pair->ord_coef, pair->shift, M, 0, 1, nzs);
         } else {
-            if (zb.nz <= 8) hipLaunchKernelGGL(k_zpart<8>, dim3(nb, C), dim3(kT), 0, call.stream, states, n, zb, partial);
-            else hipLaunchKernelGGL(k_zpart<kZBatch>, dim3(nb, C), dim3(kT), 0, call.stream, states, n, zb, partial);
+            if (zb.nz <= 8) hipLaunchKernelGGL(k_zpart<8>, dim3(C, nb), dim3(kT), 0, call.stream, states, n, zb, partial);
+            else hipLaunchKernelGGL(k_zpart<kZBatch>, dim3(C, nb), dim3(kT), 0, call.stream, states, n, zb, partial);
             if (nzs)
                 hipLaunchKernelGGL(k_finish, dim3(C), dim3(kT), 0, call.stream, partial, nb, nzs, zb, 1, 0.0,
                                    call.d_out_expect, e0, n_obs, 0, 0, call.spec, 0);
@@ -1412,13 +1446,13 @@ int measure_states(const EvalCall& call, double2* st, int C, int64_t e0, int nb,
                 mb.col[m] = 0;
             }
             if (pair) {
-                if (mb.nz <= 8) hipLaunchKernelGGL(k_zpart2<8>, dim3(nb, C), dim3(kT), 0, call.stream, pair->f, st, n, mb, partial);
-                else hipLaunchKernelGGL(k_zpart2<kZBatch>, dim3(nb, C), dim3(kT), 0, call.stream, pair->f, st, n, mb, partial);
+                if (mb.nz <= 8) hipLaunchKernelGGL(k_zpart2<8>, dim3(C, nb), dim3(kT), 0, call.stream, pair->f, st, n, mb, partial);
+                else hipLaunchKernelGGL(k_zpart2<kZBatch>, dim3(C, nb), dim3(kT), 0, call.stream, pair->f, st, n, mb, partial);
                 hipLaunchKernelGGL(k_finish2, dim3(C), dim3(kT), 0, call.stream, partial, nb, mb.nz, mb, 1, 0.0,
                                    call.d_out_marginal, pair->row0, pair->ord, pair->ord_coef, pair->shift, M, m0, 1, 0);
             } else {
-                if (mb.nz <= 8) hipLaunchKernelGGL(k_zpart<8>, dim3(nb, C), dim3(kT), 0, call.stream, st, n, mb, partial);
-                else hipLaunchKernelGGL(k_zpart<kZBatch>, dim3(nb, C), dim3(kT), 0, call.stream, st, n, mb, partial);
+                if (mb.nz <= 8) hipLaunchKernelGGL(k_zpart<8>, dim3(C, nb), dim3(kT), 0, call.stream, st, n, mb, partial);
+                else hipLaunchKernelGGL(k_zpart<kZBatch>, dim3(C, nb), dim3(kT), 0, call.stream, st, n, mb, partial);
                 hipLaunchKernelGGL(k_finish, dim3(C), dim3(kT), 0, call.stream, partial, nb, mb.nz, mb, 0, 0.0,
                                    call.d_out_marginal, e0, M, m0, 1, call.spec, 0);
             }
