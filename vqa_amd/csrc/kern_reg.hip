@@ -44,6 +44,10 @@ namespace vqa {
 #ifndef VQA_WAVES
 #define VQA_WAVES 3
 #endif
+// the same for the grouped sweeps of small circuits (one-wave workgroups)
+#ifndef VQA_GROUP_WAVES
+#define VQA_GROUP_WAVES 3
+#endif
 
 #ifdef VQA_PROF
 #define VQA_ABL(a, bit) (((a).ablate >> (bit)) & 1)
@@ -1040,7 +1044,7 @@ __device__ __forceinline__ void prep_base(const RegArgs& a, const Prog& pp, doub
     }
 }
 
-__global__ __launch_bounds__(64, VQA_WAVES) void k_reg_group(RegArgs a) {
+__global__ __launch_bounds__(64, VQA_GROUP_WAVES) void k_reg_group(RegArgs a) {
     constexpr int BLOCK = 64;
     constexpr bool SCALED = false;   // several states per wave: plain (cos, sin) lane rotations
     extern __shared__ double2 smem[];
@@ -1558,7 +1562,7 @@ int reg_engine_group(const EvalCall& call, const void* d_prog, const RegProgram&
     const int S = P.hdr.S;
     const int64_t items = (int64_t)n_samples * (int64_t)((n_live + S - 1) / S);
     const int by_lds = (int)((160 * 1024) / std::max<size_t>(lds, 1));
-    const int per_cu = std::max(1, std::min(VQA_WAVES * 4, by_lds));
+    const int per_cu = std::max(1, std::min(VQA_GROUP_WAVES * 4, by_lds));
     const int grid = (int)std::min<int64_t>(items, (int64_t)256 * per_cu);
     hipLaunchKernelGGL(k_reg_group, dim3(grid), dim3(64), lds, call.stream, a);
     VQA_HIP(hipGetLastError());
