@@ -1407,7 +1407,7 @@ int reg_engine_run(const EvalCall& call, const void* d_prog, const RegProgram& P
     // resident workgroups per CU: LDS, and the register budget of the launch bounds
     const int by_regs = std::max(1, (P.hdr.block == 1024 ? 4 : P.hdr.block == 512 ? 2 : VQA_WAVES) * 4 / (P.hdr.block / 64));
     const int by_lds = (int)((160 * 1024) / std::max<size_t>(P.lds_bytes, 1));
-    const int per_cu = std::max(1, std::min(8, std::min(by_regs, by_lds)));
+    const int per_cu = std::max(1, std::min(by_regs, by_lds));
     const int grid = (int)std::min<int64_t>(groups, (int64_t)256 * per_cu);
     switch (P.hdr.block) {
     case 64: hipLaunchKernelGGL(k_reg_eval<64>, dim3(grid), dim3(64), P.lds_bytes, call.stream, a); break;
@@ -1436,7 +1436,10 @@ int reg_engine_sweep(const EvalCall& call, const void* d_prog, const RegProgram&
     if (n_samples <= 0) return VQA_OK;
     RegArgs a = make_args(call, d_prog);
     a.E = n_samples;
-    const int per_cu = std::max<int>(1, std::min<int>(8, (int)((160 * 1024) / std::max<size_t>(P.lds_bytes_psr, 1))));
+    // resident workgroups per CU: what LDS allows, and the register budget of the launch bounds for
+    // the one- and two-wave workgroups of 10 and 11 qubits (VQA_WAVES waves per SIMD)
+    const int by_regs = P.hdr.block <= 128 ? VQA_WAVES * 4 / (P.hdr.block / 64) : 8;
+    const int per_cu = std::max<int>(1, std::min<int>(by_regs, (int)((160 * 1024) / std::max<size_t>(P.lds_bytes_psr, 1))));
     const int grid = (int)std::min<int64_t>(n_samples, (int64_t)256 * per_cu);
     const size_t ck_bytes = (size_t)grid * (P.hdr.n_ddesc + 1) * ((size_t)16 << P.hdr.n);
     const size_t rec_bytes = (size_t)grid * std::max(P.hdr.n_runs, 1) * sizeof(RunRec);
