@@ -86,6 +86,7 @@ struct RegArgs {
     RunRec* recs;      // sweep: per-workgroup run records
     const int32_t* live;  // sweep: the runs to execute, ascending (the others' outputs are filled in by the caller)
     int n_live;
+    int need_psi;      // grouped sweeps: the list holds pair runs (the unshifted state of every sample is kept)
 #ifdef VQA_PROF
     int ablate;
 #endif
@@ -812,9 +813,12 @@ __device__ __forceinline__ double measure(const double2 (&amp)[kRegAmps], const 
 // psi_norm), basev the unshifted values; rec (LDS) gives rho = the ratio of the
 // unit factors the engine left out of the two runs and (cos, sin)(kappa/2);
 // e1 = instance index of +kappa (-kappa is e1 + 1).
+// psi_lds != nullptr: psi is read from LDS instead, amplitude r of the state's thread t at
+// psi_lds[(r << T) + t] (small circuits, where the states of a workgroup share one sample's psi).
 __device__ __forceinline__ void measure_pair(double2 (&amp)[kRegAmps], unsigned psi_image, double psi_norm,
                                              const double2* rec, const double* basev, const RegArgs& a, const Prog& pp,
-                                             const Ctx& cx, double* red, unsigned& parity, int64_t e1, bool valid) {
+                                             const Ctx& cx, double* red, unsigned& parity, int64_t e1, bool valid,
+                                             const double2* psi_lds = nullptr) {
     const double nanv = __longlong_as_double(0x7ff8000000000000LL);
     unsigned kt, krb[kRegBits];
     const int t = cx.t();
@@ -825,13 +829,23 @@ __device__ __forceinline__ void measure_pair(double2 (&amp)[kRegAmps], unsigned 
     // amp <- conj(psi) phi, pr <- |phi|^2; the loads of psi run four ahead.  (The
     // scheduling fences keep that order: left alone, the compiler issues all sixteen
     // loads at once and spills the state to make room for them.)
+    if (psi_lds) {
+#pragma unroll
+        for (int r = 0; r < kRegAmps; ++r) {
+            const double2 ps = psi_lds[(r << cx.T) + t];
+            const double2 ph = amp[r];
+            pr[r] = ph.x * ph.x + ph.y * ph.y;
+            amp[r] = make_double2(ps.x * ph.x + ps.y * ph.y, ps.x * ph.y - ps.y * ph.x);
+        }
+    }
     u32x4 pv[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-        pv[r] = __builtin_amdgcn_raw_buffer_load_b128(cx.area, toff, psi_image + r * rstep, VQA_IMAGE_AUX);
+        if (!psi_lds) pv[r] = __builtin_amdgcn_raw_buffer_load_b128(cx.area, toff, psi_image + r * rstep, VQA_IMAGE_AUX);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int r = 0; r < kRegAmps; ++r) {
+        if (psi_lds) break;
         const u32x4 cur = pv[r & 3];
         const double2 ps = VQA_ABL(a, 10) ? make_double2(1.0, 0.5) : *(const double2*)&cur;
         const double2 ph = amp[r];
@@ -990,167 +1004,6 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : BLOCK == 512 ? 2 : VQA_W
     }
 }
 
-// ---- full parameter-shift sweeps of small circuits (several states per workgroup) ------
-// Below 10 qubits a workgroup (one wave) holds S = 64 / 2^(n-4) states.  As an explicit list
-// every instance would prepare all its fused 2x2s from scratch, which costs far more than the
-// gates of so small a state.  Here the S states of a workgroup are S shifts of ONE sample:
-// the unshifted tables of the sample are prepared once (and kept while the workgroup stays on
-// that sample), copied to every state, and the thread of each state patches the entries its
-// parameter enters: the fused 2x2 recomputed at the shifted angle, the phase slots in front of
-// and behind it multiplied by the ratio of new and old RZ factors, or the parameter's own
-// phase slot turned by half the shift.
-// a.E = number of samples; a.live[0 .. n_live) = the shift indices k to run (0 = unshifted,
-// 2i+1 / 2i+2 = +-shift of parameter i), ascending; output instance j * (2P+1) + k.
-// Work items (sample, chunk of S shifts) are dealt to the workgroups in contiguous ranges.
-template <bool SCALED>
-__device__ __forceinline__ void prep_base(const RegArgs& a, const Prog& pp, double2* base, double2* bag,
-                                          const double* row, int NU, int N1, int N2, int tid, int nthr) {
-    for (int k = tid; k < N1 + N2; k += nthr) {
-        const int begin = k < N1 ? pp.d1[k].begin : pp.d2[k - N1].begin;
-        const int count = k < N1 ? pp.d1[k].count : pp.d2[k - N1].count;
-        cplx ph = { 1.0, 0.0 };
-        if (count > 0) {
-            double ang = 0.0;
-            for (int j = 0; j < count; ++j) ang += elem_angle_c(pp.terms + begin + j, a.theta, row, -1, 0.0);
-            double sn, c;
-            sincos(0.5 * ang, &sn, &c);
-            ph = { c, sn };
-        }
-        base[NU + k] = make_double2(ph.x, ph.y);
-    }
-    // even U-stages first: no two entries of one round update the same phase slot
-    for (int parity = 0; parity < 2; ++parity) {
-        __syncthreads();
-        for (int u = tid; u < NU; u += nthr) {
-            if (pp.uent[u].parity != parity) continue;
-            const int d_before = pp.uent[u].d_before, d_after = pp.uent[u].d_after;
-            double2 cs;
-            cplx A, G, gp;
-            compute_uentry<SCALED>(pp, u, a.theta, row, -1, 0.0, -1, cs, A, G, gp);
-            base[u] = cs;
-            bag[2 * u] = make_double2(A.x, A.y);
-            bag[2 * u + 1] = make_double2(G.x, G.y);
-            if (d_before >= 0) {
-                const double2 p = base[NU + d_before];
-                const cplx q = cmul({ p.x, p.y }, G);
-                base[NU + d_before] = make_double2(q.x, q.y);
-            }
-            if (d_after >= 0) {
-                const double2 p = base[NU + d_after];
-                const cplx q = cmul({ p.x, p.y }, A);
-                base[NU + d_after] = make_double2(q.x, q.y);
-            }
-        }
-    }
-}
-
-__global__ __launch_bounds__(64, VQA_GROUP_WAVES) void k_reg_group(RegArgs a) {
-    constexpr int BLOCK = 64;
-    constexpr bool SCALED = false;   // several states per wave: plain (cos, sin) lane rotations
-    extern __shared__ double2 smem[];
-    const Prog pp = load_prog(a.prog);
-    const int n = pp.H->n, T = pp.H->T, S = pp.H->S;
-    const int NU = pp.H->n_uent, N1 = pp.H->n_d1, N2 = pp.H->n_d2;
-    const int tab_stride = NU + N1 + N2;
-    const int tid = threadIdx.x;
-    const int sl = tid >> T;
-    const int t = tid & ((1 << T) - 1);
-
-    double2* tabs = smem;                                  // S * tab_stride
-    double2* base = tabs + (size_t)S * tab_stride;         // unshifted tables of the current sample
-    double2* bag = base + tab_stride;                      // (A, G) of every fused 2x2 of the unshifted circuit
-    double2* xbuf = bag + 2 * (size_t)NU;
-    double* red = (double*)(xbuf + (pp.H->has_xpose ? ((size_t)1 << (n - 1)) : 0));
-    unsigned short* smask = (unsigned short*)(red + 128);
-
-    Ctx cx;
-    cx.mat = tabs + (size_t)sl * tab_stride;
-    cx.ph1 = cx.mat + NU;
-    cx.ph2 = cx.ph1 + N1;
-    cx.xbuf = (char*)xbuf;
-    cx.smask = smask;
-    cx.T = T; cx.nthr = BLOCK;
-    cx.wave = 0; cx.tmask = (1 << T) - 1;
-    cx.xc_id = -1; cx.xc_wt = 0; cx.xc_rt = 0;
-    cx.area = __builtin_amdgcn_make_buffer_rsrc((void*)nullptr, 0, 0, 0x00020000);
-    cx.image_bytes = 0;
-#ifdef VQA_PROF
-    cx.flag_mask = -1;
-#endif
-    thread_constants<BLOCK>(pp, smask, T, t, tid);
-
-    const int K = 2 * a.spec.P + 1;
-    const int NL = a.n_live;
-    const int chunks = (NL + S - 1) / S;
-    const int64_t total = a.E * chunks;
-    const int64_t w0 = total * blockIdx.x / gridDim.x, w1 = total * (blockIdx.x + 1) / gridDim.x;
-    int64_t cur = -1;
-    unsigned parity = 0;
-    for (int64_t w = w0; w < w1; ++w) {
-        const int64_t j = w / chunks;
-        const int ch = (int)(w - j * chunks);
-        int b = a.spec.sel ? a.spec.sel[j] : (int)j;
-        const bool valid = a.spec.B == 0 || (unsigned)b < (unsigned)a.spec.B;
-        if (!valid) b = 0;
-        const double* row = a.input + (size_t)b * a.n_input;
-        __syncthreads();   // the previous item is done with the tables
-        if (j != cur) {
-            prep_base<SCALED>(a, pp, base, bag, row, NU, N1, N2, tid, BLOCK);
-            cur = j;
-            __syncthreads();
-        }
-        for (int i = tid; i < S * tab_stride; i += BLOCK) {
-            const int s2 = i / tab_stride;
-            tabs[i] = base[i - s2 * tab_stride];
-        }
-        __syncthreads();
-        const int li = ch * S + sl;
-        const bool live = li < NL;
-        const int k = live ? a.live[li] : 0;
-        if (live && t == 0 && k > 0) {
-            const int i = (k - 1) >> 1;
-            const double sval = (k & 1) ? a.spec.shift : -a.spec.shift;
-            double2* tb = tabs + (size_t)sl * tab_stride;
-            const int rb = pp.params[i].ref_begin, rcnt = pp.params[i].ref_count;
-            for (int q = 0; q < rcnt; ++q) {
-                const int kind = pp.refs[rb + q].kind, index = pp.refs[rb + q].index;
-                if (kind == 0) {
-                    double2 m;
-                    cplx A, G, gp;
-                    compute_uentry<SCALED>(pp, index, a.theta, row, i, sval, -1, m, A, G, gp);
-                    tb[index] = m;
-                    const int d_before = pp.uent[index].d_before, d_after = pp.uent[index].d_after;
-                    if (d_before >= 0) {
-                        const double2 g0 = bag[2 * index + 1], p = tb[NU + d_before];
-                        const cplx f = cmul(cconj({ g0.x, g0.y }), G), r = cmul({ p.x, p.y }, f);
-                        tb[NU + d_before] = make_double2(r.x, r.y);
-                    }
-                    if (d_after >= 0) {
-                        const double2 a0 = bag[2 * index], p = tb[NU + d_after];
-                        const cplx f = cmul(cconj({ a0.x, a0.y }), A), r = cmul({ p.x, p.y }, f);
-                        tb[NU + d_after] = make_double2(r.x, r.y);
-                    }
-                } else {
-                    double sn, c;
-                    sincos(0.5 * pp.refs[rb + q].coef_sum * sval, &sn, &c);
-                    const int slot = kind == 1 ? NU + index : NU + N1 + index;
-                    const double2 p = tb[slot];
-                    const cplx r = cmul({ p.x, p.y }, { c, sn });
-                    tb[slot] = make_double2(r.x, r.y);
-                }
-            }
-        }
-        __syncthreads();
-
-        double2 amp[kRegAmps];
-#pragma unroll
-        for (int r = 0; r < kRegAmps; ++r) amp[r] = make_double2(0.0, 0.0);
-        if (t == 0) amp[0].x = 1.0;
-        run_phases<SCALED>(amp, pp, cx, 0, false, false);
-        measure(amp, a, pp, cx, red, parity, j * K + k, live, valid, nullptr);
-    }
-}
-
 // ---- full parameter-shift sweeps ------------------------------------------------------
 // a.E = number of samples; sample j = sel[j] (or j); outputs at instance
 // j * (2P+1) + k.  One state per workgroup (BLOCK = 2^T >= 64 threads).
@@ -1164,7 +1017,7 @@ __global__ __launch_bounds__(64, VQA_GROUP_WAVES) void k_reg_group(RegArgs a) {
 // then the runs one after the other, each: thread 0 undoes the previous patch
 // and applies this run's, everybody resumes from the checkpoint and measures.
 // The record of the next run is fetched while the current one computes.
-template <int BLOCK>
+template <int BLOCK, bool SCALED = true>
 __device__ __forceinline__ void make_run_record(const RegArgs& a, const Prog& pp, int r, const double* row, int NU, int N1,
                                                 RunRec* out) {
     const int i = pp.runs[r].param, variant = pp.runs[r].variant;
@@ -1182,7 +1035,7 @@ __device__ __forceinline__ void make_run_record(const RegArgs& a, const Prog& pp
         cplx A[2], G[2], gp[2];
 #pragma unroll 1
         for (int v = 0; v < 2; ++v)
-            compute_uentry<true>(pp, index, a.theta, row, (v == 1 && variant != 0) ? i : -1, shift,
+            compute_uentry<SCALED>(pp, index, a.theta, row, (v == 1 && variant != 0) ? i : -1, shift,
                                  (v == 1 && variant == 0) ? i : -1, mv[v], A[v], G[v], gp[v]);
         m = mv[1];
         fb = cmul(cconj(G[0]), G[1]);
@@ -1356,6 +1209,220 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : BLOCK == 512 ? 2 : VQA_W
     }
 }
 
+// ---- full parameter-shift sweeps of small circuits (several states per workgroup) ------
+// Below 10 qubits a workgroup (one wave) holds S = 64 / 2^(n-4) states.  As an explicit list
+// every instance would prepare all its fused 2x2s from scratch, which costs as much as the
+// gates of so small a state.  Here the S states of a workgroup are S RUNS of ONE sample (the
+// run list of the sweep kernel above: one run per parameter where both shifted values come out
+// of one propagated state, else one per shift).  Per (workgroup, sample): the unshifted tables
+// are prepared once; the unshifted circuit is run (by every state alike), its final state psi
+// goes to LDS and its values to basev.  Per chunk of S runs: the tables are copied to every
+// state, the first thread of each state patches the entries of its run -- the sweep kernel's
+// run record for a pair run; for single shifts every entry the parameter enters: the fused 2x2
+// recomputed at the shifted angle, the phase slots in front of and behind it multiplied by the
+// ratio of new and old RZ factors, or the parameter's own phase slot turned by half the shift --
+// and every state runs the circuit and measures (pairs against psi in LDS).
+// a.E = number of samples; a.live[0 .. n_live) = what to run per sample: r >= 0 = run r of the
+// run list, -(k + 1) = shift index k on its own; output instance j * (2P+1) + k.  With pair runs
+// in the list (need_psi) row 0 of a sample is written by the unshifted run of every workgroup
+// that works on the sample (same value); without, the list holds -(0 + 1) and nothing is kept
+// per sample but the tables (the cheaper form when a sample's shifts fill only a chunk or two).
+// Work items (sample, chunk of S entries) are dealt to the workgroups in contiguous ranges.
+template <bool SCALED>
+__device__ __forceinline__ void prep_base(const RegArgs& a, const Prog& pp, double2* base, double2* bag,
+                                          const double* row, int NU, int N1, int N2, int tid, int nthr) {
+    for (int k = tid; k < N1 + N2; k += nthr) {
+        const int begin = k < N1 ? pp.d1[k].begin : pp.d2[k - N1].begin;
+        const int count = k < N1 ? pp.d1[k].count : pp.d2[k - N1].count;
+        cplx ph = { 1.0, 0.0 };
+        if (count > 0) {
+            double ang = 0.0;
+            for (int j = 0; j < count; ++j) ang += elem_angle_c(pp.terms + begin + j, a.theta, row, -1, 0.0);
+            double sn, c;
+            sincos(0.5 * ang, &sn, &c);
+            ph = { c, sn };
+        }
+        base[NU + k] = make_double2(ph.x, ph.y);
+    }
+    // even U-stages first: no two entries of one round update the same phase slot
+    for (int parity = 0; parity < 2; ++parity) {
+        __syncthreads();
+        for (int u = tid; u < NU; u += nthr) {
+            if (pp.uent[u].parity != parity) continue;
+            const int d_before = pp.uent[u].d_before, d_after = pp.uent[u].d_after;
+            double2 cs;
+            cplx A, G, gp;
+            compute_uentry<SCALED>(pp, u, a.theta, row, -1, 0.0, -1, cs, A, G, gp);
+            base[u] = cs;
+            bag[2 * u] = make_double2(A.x, A.y);
+            bag[2 * u + 1] = make_double2(G.x, G.y);
+            if (d_before >= 0) {
+                const double2 p = base[NU + d_before];
+                const cplx q = cmul({ p.x, p.y }, G);
+                base[NU + d_before] = make_double2(q.x, q.y);
+            }
+            if (d_after >= 0) {
+                const double2 p = base[NU + d_after];
+                const cplx q = cmul({ p.x, p.y }, A);
+                base[NU + d_after] = make_double2(q.x, q.y);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(64, VQA_GROUP_WAVES) void k_reg_group(RegArgs a) {
+    constexpr int BLOCK = 64;
+    constexpr bool SCALED = false;   // several states per wave: plain (cos, sin) lane rotations
+    extern __shared__ double2 smem[];
+    const Prog pp = load_prog(a.prog);
+    const int n = pp.H->n, T = pp.H->T, S = pp.H->S;
+    const int NU = pp.H->n_uent, N1 = pp.H->n_d1, N2 = pp.H->n_d2;
+    const int tab_stride = NU + N1 + N2;
+    const int tid = threadIdx.x;
+    const int sl = tid >> T;
+    const int t = tid & ((1 << T) - 1);
+
+    double2* tabs = smem;                                  // S * tab_stride
+    double2* base = tabs + (size_t)S * tab_stride;         // unshifted tables of the current sample
+    double2* bag = base + tab_stride;                      // (A, G) of every fused 2x2 of the unshifted circuit
+    double2* xbuf = bag + 2 * (size_t)NU;
+    double* red = (double*)(xbuf + (pp.H->has_xpose ? ((size_t)1 << (n - 1)) : 0));
+    unsigned short* smask = (unsigned short*)(red + 128);
+    // behind the sign masks: psi (2^n amplitudes), the unshifted values, one run record per state
+    double2* psi = (double2*)((char*)smask + (((size_t)pp.H->n_sign * BLOCK * 2 + 15) & ~(size_t)15));
+    double* basev = (double*)(psi + ((size_t)1 << n));     // 79 values, squared norm of psi
+    RunRec* srec = (RunRec*)(basev + 80) + sl;
+
+    Ctx cx;
+    cx.mat = tabs + (size_t)sl * tab_stride;
+    cx.ph1 = cx.mat + NU;
+    cx.ph2 = cx.ph1 + N1;
+    cx.xbuf = (char*)xbuf;
+    cx.smask = smask;
+    cx.T = T; cx.nthr = BLOCK;
+    cx.wave = 0; cx.tmask = (1 << T) - 1;
+    cx.xc_id = -1; cx.xc_wt = 0; cx.xc_rt = 0;
+    cx.area = __builtin_amdgcn_make_buffer_rsrc((void*)nullptr, 0, 0, 0x00020000);
+    cx.image_bytes = 0;
+#ifdef VQA_PROF
+    cx.flag_mask = -1;
+#endif
+    thread_constants<BLOCK>(pp, smask, T, t, tid);
+
+    const int K = 2 * a.spec.P + 1;
+    const int NL = a.n_live;
+    const int chunks = max((NL + S - 1) / S, 1);   // (no live run: one chunk, so that row 0 is still written)
+    const int64_t total = a.E * chunks;
+    const int64_t w0 = total * blockIdx.x / gridDim.x, w1 = total * (blockIdx.x + 1) / gridDim.x;
+    int64_t cur = -1, cur_psi = -1;
+    unsigned parity = 0;
+    for (int64_t w = w0; w < w1; ++w) {
+        const int64_t j = w / chunks;
+        const int ch = (int)(w - j * chunks);
+        int b = a.spec.sel ? a.spec.sel[j] : (int)j;
+        const bool valid = a.spec.B == 0 || (unsigned)b < (unsigned)a.spec.B;
+        if (!valid) b = 0;
+        const double* row = a.input + (size_t)b * a.n_input;
+        __syncthreads();   // the previous item is done with the tables
+        if (j != cur) {
+            prep_base<SCALED>(a, pp, base, bag, row, NU, N1, N2, tid, BLOCK);
+            cur = j;
+        }
+        // pass 0 (first item of a sample when pair runs are listed): the unshifted circuit, by every
+        // state alike; state 0 keeps psi and the values.  pass 1: the chunk's entries.
+        const bool do_base = a.need_psi && j != cur_psi;
+        cur_psi = j;
+        for (int pass = do_base ? 0 : 1; pass < 2; ++pass) {
+            __syncthreads();
+            for (int i = tid; i < S * tab_stride; i += BLOCK) {
+                const int s2 = i / tab_stride;
+                tabs[i] = base[i - s2 * tab_stride];
+            }
+            __syncthreads();
+            // list entry: r >= 0 = run r of the run list; -(k + 1) = shift index k on its own (0 = unshifted)
+            const int li = ch * S + sl;
+            const bool live = pass == 0 ? sl == 0 : li < NL;
+            const int r = (pass == 1 && live) ? a.live[li] : -1;
+            int i = 0, variant = 3, kout = 0;   // variant 3: nothing to patch
+            if (r >= 0) {
+                i = pp.runs[r].param;
+                variant = pp.runs[r].variant;
+                kout = 1 + 2 * i + (variant == 2 ? 1 : 0);
+            } else if (r < -1) {
+                kout = -r - 1;
+                i = (kout - 1) >> 1;
+                variant = (kout & 1) ? 1 : 2;
+            }
+            if (live && t == 0 && variant != 3) {
+                double2* tb = tabs + (size_t)sl * tab_stride;
+                if (variant == 0) {
+                    // both shifts from one run: the sweep kernel's record (generator inserted in front of the rotation)
+                    make_run_record<BLOCK, SCALED>(a, pp, r, row, NU, N1, srec);
+                    if (srec->ids[0] >= 0) tb[srec->ids[0]] = make_double2(srec->m[0], srec->m[1]);
+                    if (srec->ids[1] >= 0) {
+                        const double2 p = tb[srec->ids[1]];
+                        const cplx q = cmul({ p.x, p.y }, { srec->fb[0], srec->fb[1] });
+                        tb[srec->ids[1]] = make_double2(q.x, q.y);
+                    }
+                    if (srec->ids[2] >= 0) {
+                        const double2 p = tb[srec->ids[2]];
+                        const cplx q = cmul({ p.x, p.y }, { srec->fa[0], srec->fa[1] });
+                        tb[srec->ids[2]] = make_double2(q.x, q.y);
+                    }
+                } else {
+                    const double sval = variant == 1 ? a.spec.shift : -a.spec.shift;
+                    const int rb = pp.params[i].ref_begin, rcnt = pp.params[i].ref_count;
+                    for (int q = 0; q < rcnt; ++q) {
+                        const int kind = pp.refs[rb + q].kind, index = pp.refs[rb + q].index;
+                        if (kind == 0) {
+                            double2 m;
+                            cplx A, G, gp;
+                            compute_uentry<SCALED>(pp, index, a.theta, row, i, sval, -1, m, A, G, gp);
+                            tb[index] = m;
+                            const int d_before = pp.uent[index].d_before, d_after = pp.uent[index].d_after;
+                            if (d_before >= 0) {
+                                const double2 g0 = bag[2 * index + 1], p = tb[NU + d_before];
+                                const cplx f = cmul(cconj({ g0.x, g0.y }), G), z = cmul({ p.x, p.y }, f);
+                                tb[NU + d_before] = make_double2(z.x, z.y);
+                            }
+                            if (d_after >= 0) {
+                                const double2 a0 = bag[2 * index], p = tb[NU + d_after];
+                                const cplx f = cmul(cconj({ a0.x, a0.y }), A), z = cmul({ p.x, p.y }, f);
+                                tb[NU + d_after] = make_double2(z.x, z.y);
+                            }
+                        } else {
+                            double sn, c;
+                            sincos(0.5 * pp.refs[rb + q].coef_sum * sval, &sn, &c);
+                            const int slot = kind == 1 ? NU + index : NU + N1 + index;
+                            const double2 p = tb[slot];
+                            const cplx z = cmul({ p.x, p.y }, { c, sn });
+                            tb[slot] = make_double2(z.x, z.y);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+
+            double2 amp[kRegAmps];
+#pragma unroll
+            for (int q = 0; q < kRegAmps; ++q) amp[q] = make_double2(0.0, 0.0);
+            if (t == 0) amp[0].x = 1.0;
+            run_phases<SCALED>(amp, pp, cx, 0, false, false);
+            if (pass == 0 && sl == 0) {
+#pragma unroll
+                for (int q = 0; q < kRegAmps; ++q) psi[(q << T) + t] = amp[q];
+            }
+            if (live && variant == 0) {
+                measure_pair(amp, 0u, basev[79], (const double2*)srec, basev, a, pp, cx, red, parity, j * K + kout, valid, psi);
+            } else {
+                const double nrm = measure(amp, a, pp, cx, red, parity, j * K + kout, live, valid,
+                                           (pass == 0 && sl == 0) ? basev : nullptr);
+                if (pass == 0 && tid == 0) basev[79] = nrm;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 static int check_reg_call(const EvalCall& call) {
@@ -1384,6 +1451,7 @@ static RegArgs make_args(const EvalCall& call, const void* d_prog) {
     a.recs = nullptr;
     a.live = nullptr;
     a.n_live = 0;
+    a.need_psi = 0;
 #ifdef VQA_PROF
     const char* abl = getenv("VQA_ABLATE");
     a.ablate = abl ? atoi(abl) : 0;
@@ -1512,11 +1580,14 @@ int reg_engine_sweep(const EvalCall& call, const void* d_prog, const RegProgram&
 }
 
 // Grouped sweeps of small circuits (k_reg_group): several states per workgroup and the tables fit.
-static size_t group_lds_bytes(const RegProgram& P) {
-    return P.lds_bytes + ((size_t)P.hdr.n_uent * 3 + P.hdr.n_d1 + P.hdr.n_d2) * 16;
+static size_t group_lds_bytes(const RegProgram& P, bool need_psi) {
+    // + the sample's unshifted tables and (A, G) pairs; with pair runs: psi, the unshifted values,
+    // one run record per state
+    return P.lds_bytes + ((size_t)P.hdr.n_uent * 3 + P.hdr.n_d1 + P.hdr.n_d2) * 16 +
+           (need_psi ? ((size_t)16 << P.hdr.n) + 80 * sizeof(double) + (size_t)P.hdr.S * sizeof(RunRec) : 0);
 }
 bool reg_engine_can_group(const RegProgram& P) {
-    return P.hdr.S > 1 && P.hdr.block == 64 && group_lds_bytes(P) <= 160 * 1024;
+    return P.hdr.S > 1 && P.hdr.block == 64 && group_lds_bytes(P, true) <= 160 * 1024;
 }
 
 int reg_engine_group(const EvalCall& call, const void* d_prog, const RegProgram& P, int n_samples) {
@@ -1525,26 +1596,42 @@ int reg_engine_group(const EvalCall& call, const void* d_prog, const RegProgram&
     if (n_samples <= 0) return VQA_OK;
     RegArgs a = make_args(call, d_prog);
     a.E = n_samples;
-    // the shift indices to run: the unshifted circuit and both shifts of every parameter that can
-    // matter for this call's observables; the rows of the others are copies of the unshifted row
+    // the runs to execute: those of the parameters that can matter for this call's observables (pair
+    // runs first, so that the states of a chunk mostly measure the same way); the rows of the other
+    // parameters are copies of the unshifted row
     ConeInfo& cone = *call.cone;
+    const int S = P.hdr.S;
+    auto list_runs = [&](std::vector<int32_t>& out, const uint8_t* mask) {
+        for (int pass = 0; pass < 2; ++pass)
+            for (int r = 0; r < P.hdr.n_runs; ++r) {
+                const int i = P.runs[r].param;
+                if (cone.dead[i] || (mask && !mask[i]) || (P.runs[r].variant == 0) != (pass == 0)) continue;
+                out.push_back(r);
+            }
+        // every shift on its own when the pair runs (plus the unshifted run they need) save too few chunks
+        int n_shifts = 1;
+        for (int i = 0; i < call.c->n_theta; ++i)
+            if (!cone.dead[i] && (!mask || mask[i])) n_shifts += 2;
+        const size_t chunks_pair = (out.size() + S - 1) / S + 1, chunks_plain = ((size_t)n_shifts + S - 1) / S;
+        if (out.empty() || 20 * chunks_pair > 17 * chunks_plain) {
+            out.clear();
+            out.push_back(-1);
+            for (int i = 0; i < call.c->n_theta; ++i)
+                if (!cone.dead[i] && (!mask || mask[i])) { out.push_back(-(2 * i + 1) - 1); out.push_back(-(2 * i + 2) - 1); }
+        }
+    };
     {
         std::lock_guard<std::mutex> lk(call.c->mu);
         if (!cone.group_built) {
-            cone.group_live_k.push_back(0);
-            for (int i = 0; i < call.c->n_theta; ++i)
-                if (!cone.dead[i]) { cone.group_live_k.push_back(2 * i + 1); cone.group_live_k.push_back(2 * i + 2); }
+            list_runs(cone.group_live_k, nullptr);
             cone.group_built = true;
         }
     }
     std::vector<int32_t> m_live, m_dead;
     if (call.param_mask) {
-        m_live.push_back(0);
-        for (int i = 0; i < call.c->n_theta; ++i) {
-            if (!call.param_mask[i]) continue;
-            if (cone.dead[i]) m_dead.push_back(i);
-            else { m_live.push_back(2 * i + 1); m_live.push_back(2 * i + 2); }
-        }
+        list_runs(m_live, call.param_mask);
+        for (int i = 0; i < call.c->n_theta; ++i)
+            if (call.param_mask[i] && cone.dead[i]) m_dead.push_back(i);
     }
     const std::vector<int32_t>& live_k = call.param_mask ? m_live : cone.group_live_k;
     const std::vector<int32_t>& dead_list = call.param_mask ? m_dead : cone.dead_list;
@@ -1555,15 +1642,16 @@ int reg_engine_group(const EvalCall& call, const void* d_prog, const RegProgram&
     int32_t* d_live = (int32_t*)ws;
     int32_t* d_dead = d_live + n_live;
     // (the cached lists live as long as the circuit; a per-call list is waited for below)
-    VQA_HIP(hipMemcpyAsync(d_live, live_k.data(), n_live * sizeof(int32_t), hipMemcpyHostToDevice, call.stream));
+    if (n_live)
+        VQA_HIP(hipMemcpyAsync(d_live, live_k.data(), n_live * sizeof(int32_t), hipMemcpyHostToDevice, call.stream));
     if (n_dead)
         VQA_HIP(hipMemcpyAsync(d_dead, dead_list.data(), n_dead * sizeof(int32_t), hipMemcpyHostToDevice, call.stream));
     a.live = d_live;
     a.n_live = (int)n_live;
-    const size_t lds = group_lds_bytes(P);
+    a.need_psi = live_k[0] >= 0;
+    const size_t lds = group_lds_bytes(P, a.need_psi != 0);
     VQA_HIP(hipFuncSetAttribute((const void*)k_reg_group, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int S = P.hdr.S;
-    const int64_t items = (int64_t)n_samples * (int64_t)((n_live + S - 1) / S);
+    const int64_t items = (int64_t)n_samples * (int64_t)std::max<size_t>((n_live + S - 1) / S, 1);
     const int by_lds = (int)((160 * 1024) / std::max<size_t>(lds, 1));
     const int per_cu = std::max(1, std::min(VQA_GROUP_WAVES * 4, by_lds));
     const int grid = (int)std::min<int64_t>(items, (int64_t)256 * per_cu);

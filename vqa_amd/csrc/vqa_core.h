@@ -135,7 +135,7 @@ struct ConeInfo {
     bool reg_built = false;
     std::vector<int32_t> reg_live_runs;      // engine 2: runs of the live parameters, in run order
     bool group_built = false;
-    std::vector<int32_t> group_live_k;       // engine 2, small circuits: shift indices of the live parameters (0 first)
+    std::vector<int32_t> group_live_k;       // engine 2, small circuits: runs of the live parameters, pair runs first
     bool hbm_built = false;
     std::vector<int32_t> hbm_ord, hbm_ord_pass, hbm_unused;   // engine 3: the sweep plan's lists without the dead
     std::vector<double> hbm_coef;
