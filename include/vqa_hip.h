@@ -106,6 +106,10 @@ int vqa_circuit_destroy(vqa_circuit* c);
 /* Introspection: qubits, ops, parameters, inputs of a circuit. */
 int vqa_circuit_info(const vqa_circuit* c, int* n_qubits, int* n_ops,
                      int* n_theta, int* n_input);
+/* The engine that serves this circuit's Z-basis calls (1..4, see vqa_set_engine), or a
+ * negative error code.  No counterpart in the reference; the host layer uses it to decide
+ * whether X/Y Pauli terms are measured behind basis-change gates on the same engine. */
+int vqa_circuit_engine(const vqa_circuit* c);
 
 /* ---- observables -------------------------------------------------------- */
 

@@ -535,6 +535,44 @@ def test_grouped_small_sweeps(n, shared):
     assert np.isfinite(e2[0]).all() and np.isfinite(m2[0]).all()
 
 
+@pytest.mark.parametrize("n", [4, 7, 10, 12])
+def test_xy_terms_behind_basis_change(n):
+    """Automatic engine, observables with X / Y / mixed Pauli strings: the host layer deals the terms
+    into qubit-wise compatible groups and measures each as Z-strings behind H / RZ(pi/2) H on the
+    register engine; explicit lists and full sweeps against the oracle, and against the LDS engine's
+    direct X/Y measurement."""
+    import os
+    c = create_ibm_HEA_ansatz(n, 2, seed=5)
+    rng = np.random.default_rng(40 + n)
+    theta = rng.uniform(0, 2 * np.pi, c.n_theta)
+    x = rng.uniform(0, np.pi, (3, n))
+    ia = c.input_angles(x)
+    h = Observable(n)
+    for q in range(n):
+        h.add_operator(0.7 - 0.1 * q, f"Z {q} Z {(q + 1) % n}")
+        h.add_operator(0.3 + 0.05 * q, f"X {q}")
+    o2 = Observable(n); o2.add_operator(0.4, f"X 0 Y {n - 1}"); o2.add_operator(-0.6, "Y 1 Z 2"); o2.add_operator(0.2, "")
+    o3 = Observable(n); o3.add_operator(1.0, "Y 0 Y 1 X 2"); o3.add_operator(0.5, "Z 3")
+    obs = [h, o2, o3]
+    assert c._basis_plan(obs) is not None and len(c._basis_plan(obs)) >= 3
+    si, sp, sv = cpu_oracle.psr_lists(3, c.n_theta)
+    want_e, want_m = cpu_oracle.eval_batch(c, theta, ia, si, sp, sv, obs_list=obs_tuples(obs), n_marg_bits=2)
+    got_e, got_m = c.psr_full(theta, ia, obs_list=obs, n_marg_bits=2)
+    assert np.abs(got_e.reshape(want_e.shape) - want_e).max() < TOL
+    assert np.abs(got_m.reshape(want_m.shape) - want_m).max() < TOL
+    pick = np.arange(0, len(si), 7)
+    d_in = c.upload_inputs(x)
+    e2, m2 = c.eval_batch(theta, d_in, si[pick], sp[pick], sv[pick], obs_list=obs, n_marg_bits=2)
+    assert np.abs(e2.cpu().numpy() - want_e[pick]).max() < TOL
+    assert np.abs(m2.cpu().numpy() - want_m[pick]).max() < TOL
+    os.environ["VQA_NO_BASIS_CHANGE"] = "1"
+    try:
+        e3, _ = c.eval_batch(theta, d_in, si[pick], sp[pick], sv[pick], obs_list=obs)
+    finally:
+        del os.environ["VQA_NO_BASIS_CHANGE"]
+    assert np.abs(e3.cpu().numpy() - e2.cpu().numpy()).max() < 1e-12
+
+
 def test_tiled_passes_against_gate_sweeps_22_qubits():
     """Beyond what the oracle finishes quickly: the tiled passes of the HBM engine against its
     one-sweep-per-gate form (independent kernels) on a 22-qubit circuit with all gate kinds."""

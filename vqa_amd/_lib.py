@@ -17,7 +17,7 @@ OK, EINVAL, ENOMEM, EHIP, EUNSUPPORTED, ENODEVICE = 0, -1, -2, -3, -4, -5
 # every symbol include/vqa_hip.h declares
 EXPORTS = (
     "vqa_version", "vqa_device_count", "vqa_last_error", "vqa_sync", "vqa_set_engine",
-    "vqa_circuit_create", "vqa_circuit_destroy", "vqa_circuit_info",
+    "vqa_circuit_create", "vqa_circuit_destroy", "vqa_circuit_info", "vqa_circuit_engine",
     "vqa_observable_create", "vqa_observable_destroy",
     "vqa_eval_batch", "vqa_eval_batch_dev", "vqa_psr_full", "vqa_psr_full_dev",
     "vqa_statevector", "vqa_sample_counts", "vqa_sample_counts_dev", "vqa_dead_parameters", "vqa_psr_params_dev",
@@ -52,6 +52,8 @@ def lib():
     L.vqa_circuit_create.argtypes = [C.c_int, vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
     L.vqa_circuit_destroy.argtypes = [vp]
     L.vqa_circuit_info.argtypes = [vp] + [C.POINTER(C.c_int)] * 4
+    L.vqa_circuit_engine.argtypes = [vp]
+    L.vqa_circuit_engine.restype = C.c_int
     L.vqa_observable_create.argtypes = [C.c_int, dp, up, up, C.c_int, C.POINTER(vp)]
     L.vqa_observable_destroy.argtypes = [vp]
     L.vqa_eval_batch.argtypes = [vp, C.c_int, dp, dp, C.c_int, ip, ip, dp, C.c_int64,

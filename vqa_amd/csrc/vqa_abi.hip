@@ -384,6 +384,11 @@ int vqa_circuit_create(int n_qubits, const vqa_op* ops, int n_ops, int n_theta, 
     return VQA_OK;
 }
 
+int vqa_circuit_engine(const vqa_circuit* c) {
+    if (!c) VQA_FAIL(VQA_EINVAL, "circuit handle is NULL");
+    return c->engine;
+}
+
 int vqa_circuit_destroy(vqa_circuit* c) {
     if (!c) return VQA_OK;
     for (auto& kv : c->dev) {

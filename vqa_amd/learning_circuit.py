@@ -15,6 +15,7 @@ raises: there is no CPU fallback.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Sequence
 
 import numpy as np
@@ -102,6 +103,7 @@ class LearningCircuit(GateList):
         d = dict(self.__dict__)
         d["_handle"] = None
         d["_handle_nops"] = -1
+        d.pop("_basis_cache", None)
         return d
 
     # ---- reference per-sample interface ------------------------------------
@@ -142,12 +144,85 @@ class LearningCircuit(GateList):
             arr[i] = o.handle().value
         return arr
 
+    # ---- X / Y Pauli terms behind basis-change gates ---------------------------
+    def _basis_plan(self, obs_list):
+        """The register engine measures in the Z basis.  When it serves this circuit and the
+        observables hold X / Y factors, their terms are dealt into groups that agree qubit by
+        qubit on the measurement basis; each group is measured as Z-strings on a copy of the
+        circuit with H (X) or RZ(pi/2), H (Y) appended to the rotated qubits:
+        <psi|Y|psi> = <G psi|Z|G psi> for G = H S^dagger, and RZ(pi/2) is S^dagger up to a phase
+        in the convention RZ(a) = diag(e^{ia/2}, e^{-ia/2}).  Group 0 is this circuit itself (pure
+        Z terms, and the marginal).  Returns None when nothing is to be split, else a list of
+        (circuit, observables), one Z-only observable per caller's observable in every group."""
+        if not any(t.xmask for o in obs_list for t in o.terms) or os.environ.get("VQA_NO_BASIS_CHANGE"):
+            return None
+        if _lib.lib().vqa_circuit_engine(self.handle()) != 2:
+            return None
+        groups = [{}]   # qubit -> 'X' | 'Y' | 'Z'
+        members = [[]]  # (observable index, coef, support mask)
+        for oi, o in enumerate(obs_list):
+            for tm in o.terms:
+                g = 0
+                if tm.xmask:
+                    for g in range(1, len(groups) + 1):
+                        if g == len(groups):
+                            groups.append({})
+                            members.append([])
+                        if all(groups[g].get(q, p) == p for q, p in tm.paulis.items()):
+                            break
+                    groups[g].update(tm.paulis)
+                members[g].append((oi, tm.coef, tm.zmask | tm.xmask))
+        cache = self.__dict__.setdefault("_basis_cache", {})
+        if cache.get("n_ops") != self.n_ops:
+            cache.clear()
+            cache["n_ops"] = self.n_ops
+        plan = []
+        for g, (basis, mem) in enumerate(zip(groups, members)):
+            if g == 0:
+                circ = self
+            else:
+                key = tuple(sorted((q, p) for q, p in basis.items() if p != "Z"))
+                circ = cache.get(key)
+                if circ is None:
+                    circ = LearningCircuit(self.n_qubit, self.device)
+                    circ._ops = list(self._ops)
+                    circ._theta = list(self._theta)
+                    circ._input_funcs = list(self._input_funcs)
+                    for q, p in key:
+                        if p == "Y":
+                            circ.add_RZ_gate(q, 0.5 * np.pi)
+                        circ.add_H_gate(q)
+                    cache[key] = circ
+            obs = [Observable(self.n_qubit) for _ in obs_list]
+            for oi, coef, mask in mem:
+                obs[oi].add_operator(coef, " ".join(f"Z {q}" for q in range(self.n_qubit) if (mask >> q) & 1))
+            plan.append((circ, obs))
+        return plan
+
+    def _run_split(self, plan, method, args, kw, n_marg_bits):
+        e_tot, m_out = None, None
+        for g, (circ, obs) in enumerate(plan):
+            k = dict(kw)
+            if g > 0:
+                k.pop("out_expect", None)
+                k.pop("out_marginal", None)
+            e, m = getattr(circ, method)(*args, obs_list=obs, n_marg_bits=n_marg_bits if g == 0 else 0, **k)
+            if g == 0:
+                e_tot, m_out = e, m
+            else:
+                e_tot += e
+        return e_tot, m_out
+
     def eval_batch(self, theta, inputs, sample_idx=None, shift_param=None, shift_val=None,
                    obs_list: Sequence[Observable] = (), n_marg_bits: int = 0, device_out: bool = False,
                    stream=None):
         """Evaluate an explicit instance list.  ``inputs``: ``[B, n_input]``
         angles (numpy: host-pointer path; torch cuda tensor: device path).
         Returns ``(expect[E, n_obs], marginal[E, 2^m] or None)``."""
+        plan = self._basis_plan(obs_list)
+        if plan is not None:
+            return self._run_split(plan, "eval_batch", (theta, inputs, sample_idx, shift_param, shift_val),
+                                   dict(device_out=device_out, stream=stream), n_marg_bits)
         torch = _torch()
         L = _lib.lib()
         n_obs, M = len(obs_list), 1 << n_marg_bits
@@ -205,6 +280,11 @@ class LearningCircuit(GateList):
         ``params``: indices of the parameters whose shifted rows are wanted (the
         others are zero or computed anyway); for sharding one circuit's shifts
         over several GPUs."""
+        plan = self._basis_plan(obs_list)
+        if plan is not None:
+            return self._run_split(plan, "psr_full", (theta, inputs),
+                                   dict(sel=sel, n_sel=n_sel, shift=shift, stream=stream, out_expect=out_expect,
+                                        out_marginal=out_marginal, params=params), n_marg_bits)
         torch = _torch()
         L = _lib.lib()
         n_obs, M, K = len(obs_list), 1 << n_marg_bits, 2 * self.n_theta + 1
