@@ -555,14 +555,19 @@ def test_xy_terms_behind_basis_change(n):
     o3 = Observable(n); o3.add_operator(1.0, "Y 0 Y 1 X 2"); o3.add_operator(0.5, "Z 3")
     obs = [h, o2, o3]
     assert c._basis_plan(obs) is not None and len(c._basis_plan(obs)) >= 3
+    assert c._basis_plan(obs, 1) is None and c._basis_plan(obs, 1 << 20) is not None   # small calls stay direct
     si, sp, sv = cpu_oracle.psr_lists(3, c.n_theta)
     want_e, want_m = cpu_oracle.eval_batch(c, theta, ia, si, sp, sv, obs_list=obs_tuples(obs), n_marg_bits=2)
-    got_e, got_m = c.psr_full(theta, ia, obs_list=obs, n_marg_bits=2)
-    assert np.abs(got_e.reshape(want_e.shape) - want_e).max() < TOL
-    assert np.abs(got_m.reshape(want_m.shape) - want_m).max() < TOL
     pick = np.arange(0, len(si), 7)
     d_in = c.upload_inputs(x)
-    e2, m2 = c.eval_batch(theta, d_in, si[pick], sp[pick], sv[pick], obs_list=obs, n_marg_bits=2)
+    os.environ["VQA_BASIS_CHANGE_ALWAYS"] = "1"
+    try:
+        got_e, got_m = c.psr_full(theta, ia, obs_list=obs, n_marg_bits=2)
+        e2, m2 = c.eval_batch(theta, d_in, si[pick], sp[pick], sv[pick], obs_list=obs, n_marg_bits=2)
+    finally:
+        del os.environ["VQA_BASIS_CHANGE_ALWAYS"]
+    assert np.abs(got_e.reshape(want_e.shape) - want_e).max() < TOL
+    assert np.abs(got_m.reshape(want_m.shape) - want_m).max() < TOL
     assert np.abs(e2.cpu().numpy() - want_e[pick]).max() < TOL
     assert np.abs(m2.cpu().numpy() - want_m[pick]).max() < TOL
     os.environ["VQA_NO_BASIS_CHANGE"] = "1"

@@ -30,7 +30,7 @@ for eng in [int(v) for v in sys.argv[4:]] or [1, 2, 3]:
               f"<Z0>[0,0]={float(e[0, 0, 0]):+.10f}", flush=True)
         c.eval_batch(theta, x[:2], obs_list=obs)
         torch.cuda.synchronize()
-        reps = max(1, (1 << 20) // B)
+        reps = max(1, min(256, (1 << 20) // B))
         t0 = time.perf_counter()
         for _ in range(reps):
             c.eval_batch(theta, x, obs_list=obs)

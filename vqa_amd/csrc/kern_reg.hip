@@ -87,6 +87,7 @@ struct RegArgs {
     const int32_t* live;  // sweep: the runs to execute, ascending (the others' outputs are filled in by the caller)
     int n_live;
     int need_psi;      // grouped sweeps: the list holds pair runs (the unshifted state of every sample is kept)
+    int split;         // sweep kernel: workgroups that share a sample's run list (>= 1)
 #ifdef VQA_PROF
     int ablate;
 #endif
@@ -1115,7 +1116,10 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : BLOCK == 512 ? 2 : VQA_W
         __syncthreads();
         if (tid == 0) s_next = atomicAdd(a.next, 1u);
         __syncthreads();
-        const int64_t j = s_next;
+        // a work item is a sample, or (few samples) one of the a.split slices of a sample's run list
+        const int64_t item = s_next;
+        const int64_t j = item / a.split;
+        const int slice = (int)(item - j * a.split);
 #ifdef VQA_PROF
         if (tid < 16) {
             if (s_stamp[tid]) atomicAdd(&g_stamp[tid], s_stamp[tid]);
@@ -1138,9 +1142,10 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : BLOCK == 512 ? 2 : VQA_W
         // run -1 is the unshifted circuit; thread 0 keeps what the current patch replaced
         int old_m = -1, old_b = -1, old_a = -1;
         double2 nx = make_double2(0, 0);
-        const int NL = a.n_live;
+        const int lo = (int)((int64_t)a.n_live * slice / a.split), NL = (int)((int64_t)a.n_live * (slice + 1) / a.split) - lo;
+        const int32_t* live = a.live + lo;
         for (int ri = -1; ri <= NL; ++ri) {
-            const int r = ri < 0 ? -1 : ri < NL ? a.live[ri] : NR;
+            const int r = ri < 0 ? -1 : ri < NL ? live[ri] : NR;
             VQA_STAMP0
             __syncthreads();   // the previous run is over (tables free); its successor's record is in pz
             int id_m = -1, id_b = -1, id_a = -1, mode = 0, kout = 0, rdiag = -1, rpc = 0;
@@ -1177,7 +1182,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : BLOCK == 512 ? 2 : VQA_W
             __syncthreads();
             VQA_STAMP(1)
             // the next run's record travels while this run computes
-            if (ri + 1 < NL && (tid & 63) < 8) nx = recs[(size_t)a.live[ri + 1] * 8 + (tid & 63)];
+            if (ri + 1 < NL && (tid & 63) < 8) nx = recs[(size_t)live[ri + 1] * 8 + (tid & 63)];
 
             double2 amp[kRegAmps];
             int pc0 = 0;
@@ -1452,6 +1457,7 @@ static RegArgs make_args(const EvalCall& call, const void* d_prog) {
     a.live = nullptr;
     a.n_live = 0;
     a.need_psi = 0;
+    a.split = 1;
 #ifdef VQA_PROF
     const char* abl = getenv("VQA_ABLATE");
     a.ablate = abl ? atoi(abl) : 0;
@@ -1508,7 +1514,13 @@ int reg_engine_sweep(const EvalCall& call, const void* d_prog, const RegProgram&
     // the one- and two-wave workgroups of 10 and 11 qubits (VQA_WAVES waves per SIMD)
     const int by_regs = P.hdr.block <= 128 ? VQA_WAVES * 4 / (P.hdr.block / 64) : 8;
     const int per_cu = std::max<int>(1, std::min<int>(by_regs, (int)((160 * 1024) / std::max<size_t>(P.lds_bytes_psr, 1))));
-    const int grid = (int)std::min<int64_t>(n_samples, (int64_t)256 * per_cu);
+    // Few samples: the run list of a sample is cut into slices for different workgroups, each of
+    // which runs the unshifted circuit for its own checkpoints first (a single circuit, the VQE
+    // case, would otherwise keep one workgroup busy and the rest of the GPU idle).
+    const int64_t slots = (int64_t)256 * per_cu;
+    const int64_t n_runs_max = std::max(P.hdr.n_runs, 1);
+    const int split = (int)std::max<int64_t>(1, std::min<int64_t>(slots / n_samples, n_runs_max));
+    const int grid = (int)std::min<int64_t>((int64_t)n_samples * split, slots);
     const size_t ck_bytes = (size_t)grid * (P.hdr.n_ddesc + 1) * ((size_t)16 << P.hdr.n);
     const size_t rec_bytes = (size_t)grid * std::max(P.hdr.n_runs, 1) * sizeof(RunRec);
     // the runs of the parameters that can matter for this call's observables; the rows of the
@@ -1546,6 +1558,7 @@ int reg_engine_sweep(const EvalCall& call, const void* d_prog, const RegProgram&
     a.recs = (RunRec*)((char*)ws + 256 + live_bytes + ck_bytes);
     a.live = d_live;
     a.n_live = (int)n_live;
+    a.split = (int)std::max<size_t>(1, std::min<size_t>((size_t)split, n_live));
     VQA_HIP(hipMemsetAsync(a.next, 0, 256, call.stream));
     // (the lists live as long as the circuit: the asynchronous copies may read them after this returns)
     if (n_live)

@@ -145,7 +145,7 @@ class LearningCircuit(GateList):
         return arr
 
     # ---- X / Y Pauli terms behind basis-change gates ---------------------------
-    def _basis_plan(self, obs_list):
+    def _basis_plan(self, obs_list, instances=None):
         """The register engine measures in the Z basis.  When it serves this circuit and the
         observables hold X / Y factors, their terms are dealt into groups that agree qubit by
         qubit on the measurement basis; each group is measured as Z-strings on a copy of the
@@ -155,6 +155,11 @@ class LearningCircuit(GateList):
         Z terms, and the marginal).  Returns None when nothing is to be split, else a list of
         (circuit, observables), one Z-only observable per caller's observable in every group."""
         if not any(t.xmask for o in obs_list for t in o.terms) or os.environ.get("VQA_NO_BASIS_CHANGE"):
+            return None
+        # a call or two more per batch: below about 2^20 amplitudes of work (a single small circuit)
+        # the direct X/Y measurement of the LDS / streaming engine is a few tenths of a millisecond faster
+        # (VQA_BASIS_CHANGE_ALWAYS: tests)
+        if instances is not None and (int(instances) << self.n_qubit) < (1 << 20) and not os.environ.get("VQA_BASIS_CHANGE_ALWAYS"):
             return None
         if _lib.lib().vqa_circuit_engine(self.handle()) != 2:
             return None
@@ -219,7 +224,13 @@ class LearningCircuit(GateList):
         """Evaluate an explicit instance list.  ``inputs``: ``[B, n_input]``
         angles (numpy: host-pointer path; torch cuda tensor: device path).
         Returns ``(expect[E, n_obs], marginal[E, 2^m] or None)``."""
-        plan = self._basis_plan(obs_list)
+        if sample_idx is not None:
+            n_inst = len(sample_idx)
+        elif shift_param is not None:
+            n_inst = len(shift_param)
+        else:
+            n_inst = 1 if inputs is None else max(int(inputs.shape[0]), 1)
+        plan = self._basis_plan(obs_list, n_inst)
         if plan is not None:
             return self._run_split(plan, "eval_batch", (theta, inputs, sample_idx, shift_param, shift_val),
                                    dict(device_out=device_out, stream=stream), n_marg_bits)
@@ -280,7 +291,8 @@ class LearningCircuit(GateList):
         ``params``: indices of the parameters whose shifted rows are wanted (the
         others are zero or computed anyway); for sharding one circuit's shifts
         over several GPUs."""
-        plan = self._basis_plan(obs_list)
+        n_rows = n_sel if n_sel is not None else len(sel) if sel is not None else (1 if inputs is None else max(int(inputs.shape[0]), 1))
+        plan = self._basis_plan(obs_list, n_rows * (2 * self.n_theta + 1))
         if plan is not None:
             return self._run_split(plan, "psr_full", (theta, inputs),
                                    dict(sel=sel, n_sel=n_sel, shift=shift, stream=stream, out_expect=out_expect,
