@@ -60,6 +60,25 @@ def test_circuit_create_validates_without_gpu():
     assert L.vqa_circuit_destroy(None) == 0
 
 
+def test_circuit_engine_choice_without_gpu():
+    """The engine that serves Z-basis calls, by register size (automatic choice): LDS below four
+    qubits, registers up to fourteen, HBM tiles beyond; NULL handle is an error."""
+    L = _lib.lib()
+    assert L.vqa_set_engine(0) == 0
+    for n, want in ((3, 1), (4, 2), (9, 2), (12, 2), (14, 2), (15, 3), (22, 3)):
+        g = GateList(n)
+        for q in range(n):
+            g.add_H_gate(q); g.add_parametric_RY_gate(q, 0.1 * q)
+        for q in range(n - 1):
+            g.add_CZ_gate(q, q + 1)
+        ops = g.op_table()
+        h = C.c_void_p()
+        assert L.vqa_circuit_create(n, _lib.nptr(ops), len(ops), n, 0, C.byref(h)) == 0
+        assert L.vqa_circuit_engine(h) == want, n
+        assert L.vqa_circuit_destroy(h) == 0
+    assert L.vqa_circuit_engine(None) == _lib.EINVAL
+
+
 def test_observable_create_validates():
     L = _lib.lib()
     h = C.c_void_p()
