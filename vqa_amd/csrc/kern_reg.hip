@@ -1339,9 +1339,9 @@ __global__ __launch_bounds__(64, VQA_GROUP_WAVES) void k_reg_group(RegArgs a) {
         cur_psi = j;
         for (int pass = do_base ? 0 : 1; pass < 2; ++pass) {
             __syncthreads();
-            for (int i = tid; i < S * tab_stride; i += BLOCK) {
-                const int s2 = i / tab_stride;
-                tabs[i] = base[i - s2 * tab_stride];
+            for (int i = tid; i < tab_stride; i += BLOCK) {
+                const double2 v = base[i];
+                for (int s2 = 0; s2 < S; ++s2) tabs[s2 * tab_stride + i] = v;
             }
             __syncthreads();
             // list entry: r >= 0 = run r of the run list; -(k + 1) = shift index k on its own (0 = unshifted)
