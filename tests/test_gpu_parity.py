@@ -578,6 +578,38 @@ def test_xy_terms_behind_basis_change(n):
     assert np.abs(e3.cpu().numpy() - e2.cpu().numpy()).max() < 1e-12
 
 
+@pytest.mark.parametrize("n", [4, 6, 9, 10, 12])
+@pytest.mark.parametrize("n_par", [0, 1, 3])
+def test_sweeps_of_tiny_parameter_sets(n, n_par):
+    """Sweeps whose run list is empty or shorter than a chunk / a slice: no parameter at all, one
+    parameter in a circuit without a diagonal stage, three parameters of which one drives nothing;
+    one sample and several."""
+    set_engine("reg")
+    c = LearningCircuit(n)
+    for q in range(n):
+        c.add_input_RY_gate(q, lambda x, q=q: x[q % len(x)])
+    if n_par >= 1:
+        c.add_parametric_RX_gate(n - 1, 0.4)
+    if n_par >= 3:
+        for q in range(n - 1):
+            c.add_CZ_gate(q, q + 1)
+        c.add_parametric_RY_gate(0, 0.2)
+        c._theta.append(0.1)                       # a parameter that drives no gate
+        c.add_H_gate(1)
+    rng = np.random.default_rng(n + n_par)
+    theta = rng.uniform(-3, 3, c.n_theta)
+    zz = Observable(n); zz.add_operator(0.8, f"Z 0 Z {n - 1}"); zz.add_operator(-0.3, "Z 1")
+    for B in (1, 5):
+        x = rng.uniform(0, np.pi, (B, 2))
+        ia = c.input_angles(x)
+        si, sp, sv = cpu_oracle.psr_lists(B, c.n_theta)
+        want_e, want_m = cpu_oracle.eval_batch(c, theta, ia, si, sp, sv, obs_list=obs_tuples([zz]), n_marg_bits=2)
+        got_e, got_m = c.psr_full(theta, ia, obs_list=[zz], n_marg_bits=2)
+        assert got_e.shape == (B, 2 * c.n_theta + 1, 1)
+        assert np.abs(got_e.reshape(want_e.shape) - want_e).max() < TOL
+        assert np.abs(got_m.reshape(want_m.shape) - want_m).max() < TOL
+
+
 def test_tiled_passes_against_gate_sweeps_22_qubits():
     """Beyond what the oracle finishes quickly: the tiled passes of the HBM engine against its
     one-sweep-per-gate form (independent kernels) on a 22-qubit circuit with all gate kinds."""
