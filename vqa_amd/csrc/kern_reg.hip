@@ -134,6 +134,7 @@ struct Prog {
     const VQA_CAS ParamInfo* params;
     const VQA_CAS PatchRef* refs;
     const VQA_CAS RunInfo* runs;
+    const VQA_CAS int32_t* dep;
 };
 
 __device__ __forceinline__ Prog load_prog(const char* blob) {
@@ -152,6 +153,7 @@ __device__ __forceinline__ Prog load_prog(const char* blob) {
     p.params = to_const<ParamInfo>(blob + p.H->off_params);
     p.refs = to_const<PatchRef>(blob + p.H->off_refs);
     p.runs = to_const<RunInfo>(blob + p.H->off_runs);
+    p.dep = to_const<int32_t>(blob + p.H->off_dep);
     return p;
 }
 
@@ -261,9 +263,15 @@ __device__ __forceinline__ void compute_uentry(const Prog& pp, int u, const doub
 // diagonal stages with the RZ factors of the neighbouring 2x2s merged in.
 // Instance of state s2 is e0 + s2 (explicit list) or the unshifted circuit of
 // sample e0 + s2 (sweep).
+// ctab (explicit lists; null otherwise): rotation data, A and G of every input-free fused 2x2 at
+// the unshifted parameters, worked out once per launch.  The entries are then prepared in three
+// homogeneous loops (a wave that mixed cached and computed entries would run the full
+// computation for its few uncached lanes anyway): the input-dependent entries are computed,
+// the input-free ones copied, and an instance whose shift touches an input-free entry
+// recomputes that one entry and corrects the phase slots around it.
 template <bool SWEEP, bool SCALED>
 __device__ __forceinline__ void prep_tables(const RegArgs& a, const Prog& pp, double2* tabs, int64_t e0, int S,
-                                            int NU, int N1, int N2, int tid, int nthr) {
+                                            int NU, int N1, int N2, int tid, int nthr, const double2* ctab = nullptr) {
     const int tab_stride = NU + N1 + N2;
     auto decode = [&](int64_t e2, int& b, int& sparam, double& sval) {
         if (SWEEP) {
@@ -299,10 +307,31 @@ __device__ __forceinline__ void prep_tables(const RegArgs& a, const Prog& pp, do
     }
     // phases 1, 2: even U-stages first, so that no two entries of one phase
     // update the same phase-table slot
+    const int ND = ctab ? pp.H->n_dep : NU;   // entries to compute per state
     for (int parity = 0; parity < 2; ++parity) {
         __syncthreads();
-        for (int i = tid; i < S * NU; i += nthr) {
-            const int s2 = i / NU, u = i - s2 * NU;
+        if (ctab) {
+            // the input-free entries: copies (same parity rule, other entries than the loop below)
+            for (int i = tid; i < S * NU; i += nthr) {
+                const int s2 = i / NU, u = i - s2 * NU;
+                if (pp.uent[u].parity != parity || !pp.uent[u].input_free || e0 + s2 >= a.E) continue;
+                const int d_before = pp.uent[u].d_before, d_after = pp.uent[u].d_after;
+                double2* tb = tabs + (size_t)s2 * tab_stride;
+                tb[u] = ctab[3 * u];
+                if (d_before >= 0) {
+                    const double2 p = tb[NU + d_before], g = ctab[3 * u + 2];
+                    const cplx q = cmul({ p.x, p.y }, { g.x, g.y });
+                    tb[NU + d_before] = make_double2(q.x, q.y);
+                }
+                if (d_after >= 0) {
+                    const double2 p = tb[NU + d_after], g = ctab[3 * u + 1];
+                    const cplx q = cmul({ p.x, p.y }, { g.x, g.y });
+                    tb[NU + d_after] = make_double2(q.x, q.y);
+                }
+            }
+        }
+        for (int i = tid; i < S * ND; i += nthr) {
+            const int s2 = i / ND, u = ctab ? pp.dep[i - s2 * ND] : i - s2 * ND;
             const int64_t e2 = e0 + s2;
             if (pp.uent[u].parity != parity || e2 >= a.E) continue;
             const int d_before = pp.uent[u].d_before, d_after = pp.uent[u].d_after;
@@ -324,6 +353,40 @@ __device__ __forceinline__ void prep_tables(const RegArgs& a, const Prog& pp, do
                 const double2 p = tb[NU + d_after];
                 const cplx q = cmul({ p.x, p.y }, A);
                 tb[NU + d_after] = make_double2(q.x, q.y);
+            }
+        }
+    }
+    if (ctab) {
+        // shifted instances: the input-free entries their parameter enters (one thread per state)
+        __syncthreads();
+        for (int s2 = tid; s2 < S; s2 += nthr) {
+            const int64_t e2 = e0 + s2;
+            if (e2 >= a.E) continue;
+            int b, sparam;
+            double sval;
+            decode(e2, b, sparam, sval);
+            if (sparam < 0) continue;
+            const double* row = a.input + (size_t)b * a.n_input;
+            double2* tb = tabs + (size_t)s2 * tab_stride;
+            const int rb = pp.params[sparam].ref_begin, rcnt = pp.params[sparam].ref_count;
+            for (int q = 0; q < rcnt; ++q) {
+                const int u = pp.refs[rb + q].index;
+                if (pp.refs[rb + q].kind != 0 || !pp.uent[u].input_free) continue;
+                double2 cs;
+                cplx A, G, gp;
+                compute_uentry<SCALED>(pp, u, a.theta, row, sparam, sval, -1, cs, A, G, gp);
+                tb[u] = cs;
+                const int d_before = pp.uent[u].d_before, d_after = pp.uent[u].d_after;
+                if (d_before >= 0) {
+                    const double2 g0 = ctab[3 * u + 2], p = tb[NU + d_before];
+                    const cplx f = cmul(cconj({ g0.x, g0.y }), G), z = cmul({ p.x, p.y }, f);
+                    tb[NU + d_before] = make_double2(z.x, z.y);
+                }
+                if (d_after >= 0) {
+                    const double2 a0 = ctab[3 * u + 1], p = tb[NU + d_after];
+                    const cplx f = cmul(cconj({ a0.x, a0.y }), A), z = cmul({ p.x, p.y }, f);
+                    tb[NU + d_after] = make_double2(z.x, z.y);
+                }
             }
         }
     }
@@ -981,6 +1044,21 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : BLOCK == 512 ? 2 : VQA_W
 #endif
 
     thread_constants<BLOCK>(pp, smask, T, t, tid);
+    // the input-free fused 2x2s at the unshifted parameters, once per launch (several states per
+    // workgroup only: with one state the preparation is a single round of the workgroup either way)
+    double2* ctab = nullptr;
+    if (BLOCK == 64 && S > 1) {
+        ctab = (double2*)((char*)smask + (((size_t)pp.H->n_sign * BLOCK * 2 + 15) & ~(size_t)15));
+        for (int u = tid; u < NU; u += BLOCK) {
+            if (!pp.uent[u].input_free) continue;
+            double2 cs;
+            cplx A, G, gp;
+            compute_uentry<SCALED>(pp, u, a.theta, a.input, -1, 0.0, -1, cs, A, G, gp);
+            ctab[3 * u] = cs;
+            ctab[3 * u + 1] = make_double2(A.x, A.y);
+            ctab[3 * u + 2] = make_double2(G.x, G.y);
+        }
+    }
 
     unsigned parity = 0;
     for (int64_t e0 = (int64_t)blockIdx.x * S; e0 < a.E; e0 += (int64_t)gridDim.x * S) {
@@ -993,7 +1071,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : BLOCK == 512 ? 2 : VQA_W
             valid = decode_eval(a.spec, e, b_, sp_, sv_);
         }
         __syncthreads();
-        prep_tables<false, SCALED>(a, pp, tabs, e0, S, NU, N1, N2, tid, BLOCK);
+        prep_tables<false, SCALED>(a, pp, tabs, e0, S, NU, N1, N2, tid, BLOCK, ctab);
         __syncthreads();
 
         double2 amp[kRegAmps];
@@ -1596,7 +1674,7 @@ int reg_engine_sweep(const EvalCall& call, const void* d_prog, const RegProgram&
 static size_t group_lds_bytes(const RegProgram& P, bool need_psi) {
     // + the sample's unshifted tables and (A, G) pairs; with pair runs: psi, the unshifted values,
     // one run record per state
-    return P.lds_bytes + ((size_t)P.hdr.n_uent * 3 + P.hdr.n_d1 + P.hdr.n_d2) * 16 +
+    return P.lds_bytes + ((size_t)P.hdr.n_d1 + P.hdr.n_d2) * 16 +   // (lds_bytes counts 3 entries per fused 2x2 already)
            (need_psi ? ((size_t)16 << P.hdr.n) + 80 * sizeof(double) + (size_t)P.hdr.S * sizeof(RunRec) : 0);
 }
 bool reg_engine_can_group(const RegProgram& P) {

@@ -238,6 +238,10 @@ bool reg_compile(int n, int n_theta, const std::vector<vqa_op>& gate_list, RegPr
             P.elems.insert(P.elems.end(), kv.second.begin(), kv.second.end());
             e.d_before = e.d_after = -1;
             e.parity = u & 1;
+            e.input_free = 1;
+            for (const ElemGate& g : kv.second)
+                if (g.src == VQA_SRC_INPUT) e.input_free = 0;
+            if (!e.input_free) P.dep.push_back((int32_t)P.uent.size());
             uidx[u][kv.first] = (int)P.uent.size();
             P.uent.push_back(e);
             ++P.n_dense_gates;
@@ -545,7 +549,9 @@ bool reg_compile(int n, int n_theta, const std::vector<vqa_op>& gate_list, RegPr
     const size_t tab1 = ((size_t)H.n_uent + H.n_d1 + H.n_d2) * 16;
     const size_t xbuf = H.has_xpose ? ((size_t)8 << n) : 0;  // half of the state at a time
     const size_t fixed = 128 * sizeof(double) + (((size_t)H.n_sign * H.block * 2 + 15) & ~(size_t)15);
-    P.lds_bytes = (size_t)H.S * tab1 + xbuf + fixed;
+    H.n_dep = (int)P.dep.size();
+    // (explicit-list kernel: + the launch-wide cache of the input-free fused 2x2s, three entries each)
+    P.lds_bytes = (size_t)H.S * tab1 + xbuf + fixed + (size_t)H.n_uent * 48;
     P.lds_bytes_psr = tab1 + xbuf + fixed + 16 * 16 + 80 * sizeof(double);  // + run record, unshifted values
     // (64 bytes of margin for the kernels' few statically allocated words)
     if (std::max(P.lds_bytes, P.lds_bytes_psr) + 64 > 160 * 1024) { *why = "per-evaluation tables do not fit LDS"; return false; }
@@ -567,6 +573,7 @@ bool reg_compile(int n, int n_theta, const std::vector<vqa_op>& gate_list, RegPr
     while (P.blob.size() % 64) P.blob.push_back(0);   // a phase descriptor is one 64-byte scalar load
     H.off_phases = place(P.blob, P.phases);
     H.off_runs = place(P.blob, P.runs);
+    H.off_dep = place(P.blob, P.dep);
     while (P.blob.size() % 16) P.blob.push_back(0);
     H.total_bytes = (int64_t)P.blob.size();
     memcpy(P.blob.data(), &H, sizeof(H));

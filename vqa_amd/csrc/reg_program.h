@@ -82,6 +82,8 @@ struct UEntry {
     int32_t d_after;   // ph1 slot that absorbs e^{i alpha/2} (-1: dropped)
     int32_t parity;    // U-stage index & 1 (the two preparation phases)
     int32_t on_lane;   // 1: applied while the qubit sits on a lane bit, 0: on a register bit
+    int32_t input_free;  // 1: no gate of the entry takes its angle from the input row (same 2x2 for every sample)
+    int32_t pad;
 };
 
 // one single-qubit phase slot of a D-stage: exp(+i/2 * sum of angle terms) on
@@ -171,11 +173,11 @@ struct RegHeader {
     int32_t n_elems, n_terms, n_ops, n_ddesc, n_xdesc, n_pairs, n_sign, n_params, n_refs, n_phases;
     int32_t n_runs;
     int32_t has_xpose;
-    int32_t pad;
+    int32_t n_dep;               // fused 2x2s that depend on the input row (dep[] lists them)
     int8_t final_qubit_at_pos[kMaxPos];
     // byte offsets of the arrays inside the device blob
     int64_t off_elems, off_uent, off_d1, off_d2, off_terms, off_ops, off_ddesc, off_xdesc, off_pairs,
-        off_signs, off_params, off_refs, off_phases, off_runs;
+        off_signs, off_params, off_refs, off_phases, off_runs, off_dep;
     int64_t total_bytes;
 };
 
@@ -196,6 +198,7 @@ struct RegProgram {
     std::vector<ParamInfo> params;
     std::vector<PatchRef> refs;
     std::vector<RunInfo> runs;
+    std::vector<int32_t> dep;      // the U-entries with input_free == 0
     std::vector<char> blob;  // header + arrays, as uploaded
     size_t lds_bytes = 0;      // explicit-list kernel (S states per workgroup)
     size_t lds_bytes_psr = 0;  // parameter-shift kernel (one state per workgroup)
