@@ -246,6 +246,44 @@ def test_headline_full_batch_properties():
     assert np.abs(e2.cpu().numpy().reshape(len(sub) * K, 1)[pick] - want).max() < TOL
 
 
+def test_regressor_config_full_batch_properties():
+    """The sin(x) regressor's configuration at full size (6 qubits, depth 5, 4096 samples, one feature):
+    the grouped sweep of the whole mini-batch is normalised, consistent between expectation and
+    marginal, equal to the sweep of a subset, to the same instances as an explicit list, to the
+    oracle on a seeded sample of instances, and its shifted rows obey the parameter-shift identity
+    against a central difference."""
+    import torch
+    c = create_ibm_HEA_ansatz(6, 5, seed=0)
+    rng = np.random.default_rng(1)
+    B = 4096
+    theta = rng.uniform(0, 2 * np.pi, c.n_theta)
+    x = rng.uniform(-1, 1, (B, 1))
+    d_in = c.upload_inputs(x)
+    z0 = Observable(6); z0.add_operator(1.0, "Z 0")
+    e, m = c.psr_full(theta, d_in, n_sel=B, obs_list=[z0], n_marg_bits=2)
+    K = 2 * c.n_theta + 1
+    assert e.shape == (B, K, 1)
+    assert bool(torch.isfinite(e).all()) and bool(torch.isfinite(m).all())
+    assert float((m.sum(dim=2) - 1).abs().max()) < TOL
+    assert float((e[:, :, 0] - (m[:, :, 0] - m[:, :, 1] + m[:, :, 2] - m[:, :, 3])).abs().max()) < TOL
+    sub = np.sort(rng.choice(B, 64, replace=False)).astype(np.int32)
+    e2, _ = c.psr_full(theta, d_in, sel=sub, obs_list=[z0])
+    assert float((e2 - e[torch.from_numpy(sub.astype(np.int64)).cuda()]).abs().max()) < TOL
+    si, sp, sv = cpu_oracle.psr_lists(len(sub), c.n_theta, sel=sub)
+    e3, _ = c.eval_batch(theta, d_in, si, sp, sv, obs_list=[z0])
+    assert float((e3.reshape(len(sub), K, 1) - e2).abs().max()) < TOL
+    pick = rng.choice(len(si), 400, replace=False)
+    want, _ = cpu_oracle.eval_batch(c, theta, c.input_angles(x), si[pick], sp[pick], sv[pick], obs_list=obs_tuples([z0]))
+    assert np.abs(e2.cpu().numpy().reshape(len(sub) * K, 1)[pick] - want).max() < TOL
+    e_host = e[:8].cpu().numpy()[:, :, 0]
+    for i in (0, 17, c.n_theta - 1):
+        h = 1e-5
+        fd, _ = c.eval_batch(theta, d_in, np.repeat(np.arange(8, dtype=np.int32), 2), np.full(16, i, np.int32),
+                             np.tile([h, -h], 8), obs_list=[z0])
+        fd = fd.cpu().numpy().reshape(8, 2)
+        assert np.abs(0.5 * (e_host[:, 2 * i + 1] - e_host[:, 2 * i + 2]) - (fd[:, 0] - fd[:, 1]) / (2 * h)).max() < 1e-8
+
+
 def test_twenty_qubit_sweep_against_explicit_list():
     """The 20-qubit configuration's circuit (depth 8, 900 gates, 540 parameters): the streaming
     engine's full sweep of one sample against its explicit-list form on a seeded subset of the 1081
