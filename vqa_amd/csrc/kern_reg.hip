@@ -44,9 +44,11 @@ namespace vqa {
 #ifndef VQA_WAVES
 #define VQA_WAVES 3
 #endif
-// the same for the grouped sweeps of small circuits (one-wave workgroups)
+// the same for the grouped sweeps of small circuits (one-wave workgroups).  Measured at 6 / 8 / 9
+// qubits: 2 (no spills) 4.03M / 1.81M / 614k gradients/s, 3 (a few spills) 3.82M / 1.48M / 571k,
+// 4 and 5 slower still.
 #ifndef VQA_GROUP_WAVES
-#define VQA_GROUP_WAVES 3
+#define VQA_GROUP_WAVES 2
 #endif
 
 #ifdef VQA_PROF
