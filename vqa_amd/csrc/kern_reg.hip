@@ -44,6 +44,10 @@ namespace vqa {
 #ifndef VQA_WAVES
 #define VQA_WAVES 3
 #endif
+// the same for the sweep kernel's one- and two-wave workgroups (10 and 11 qubits)
+#ifndef VQA_SMALL_WAVES
+#define VQA_SMALL_WAVES 3
+#endif
 // the same for the grouped sweeps of small circuits (one-wave workgroups).  Measured at 6 / 8 / 9
 // qubits: 2 (no spills) 4.03M / 1.81M / 614k gradients/s, 3 (a few spills) 3.82M / 1.48M / 571k,
 // 4 and 5 slower still.
@@ -1149,7 +1153,7 @@ __device__ __forceinline__ void make_run_record(const RegArgs& a, const Prog& pp
 }
 
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : BLOCK == 512 ? 2 : VQA_WAVES) void k_reg_psr(RegArgs a) {
+__global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : BLOCK == 512 ? 2 : BLOCK <= 128 ? VQA_SMALL_WAVES : VQA_WAVES) void k_reg_psr(RegArgs a) {
     extern __shared__ double2 smem[];
     const Prog pp = load_prog(a.prog);
     const int n = pp.H->n, T = pp.H->T;
@@ -1592,7 +1596,7 @@ int reg_engine_sweep(const EvalCall& call, const void* d_prog, const RegProgram&
     a.E = n_samples;
     // resident workgroups per CU: what LDS allows, and the register budget of the launch bounds for
     // the one- and two-wave workgroups of 10 and 11 qubits (VQA_WAVES waves per SIMD)
-    const int by_regs = P.hdr.block <= 128 ? VQA_WAVES * 4 / (P.hdr.block / 64) : 8;
+    const int by_regs = P.hdr.block <= 128 ? VQA_SMALL_WAVES * 4 / (P.hdr.block / 64) : 8;
     const int per_cu = std::max<int>(1, std::min<int>(by_regs, (int)((160 * 1024) / std::max<size_t>(P.lds_bytes_psr, 1))));
     // Few samples: the run list of a sample is cut into slices for different workgroups, each of
     // which runs the unshifted circuit for its own checkpoints first (a single circuit, the VQE
