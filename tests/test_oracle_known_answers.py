@@ -135,9 +135,16 @@ def test_reference_closure_quirk():
     assert row[3] == pytest.approx((np.pi - x[1]) * (np.pi - x[0]))
     c2 = create_ibm_HEA_ansatz(4, 1, circuit_cls=GateList, reference_closure=False)
     assert c2.input_row(x)[3] == pytest.approx((np.pi - x[1]) * (np.pi - x[2]))
+    # Jerbi: gate order RZ(x0); RZ(x1), ZZ(1,0); RZ(x2), ZZ(2,0), ZZ(2,1); ...  The lambdas' `j` is the
+    # builder's one local cell: the CZ ring of a trainable layer leaves it at 0, without trainable
+    # layers the feature-map loop leaves it at n-2 (tests/golden/gate_lists.json holds the
+    # reference builder's own values)
     cj = create_jerbi_ansatz(4, 1, circuit_cls=GateList)
-    # gate order: RZ(x0); RZ(x1), ZZ(1,0); RZ(x2), ZZ(2,0), ZZ(2,1); ...   j seen = n-2 = 2
-    assert cj.input_row(x)[2] == pytest.approx(x[1] * x[2])
+    assert cj.input_row(x)[2] == pytest.approx(x[1] * x[0])
+    cj0 = create_jerbi_ansatz(4, 0, circuit_cls=GateList)
+    assert cj0.input_row(x)[2] == pytest.approx(x[1] * x[2])
+    cjp = create_jerbi_ansatz(4, 1, circuit_cls=GateList, reference_closure=False)
+    assert cjp.input_row(x)[5] == pytest.approx(x[2] * x[1])
 
 
 def test_ka5_parameter_shift_equals_derivative():

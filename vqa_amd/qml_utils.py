@@ -8,19 +8,8 @@ the reference (4-qubit Iris classifier, 28-qubit Pauli-sum circuit).
 """
 from __future__ import annotations
 
-import time
-from functools import reduce
-import operator
-
 import numpy as np
 from numpy.random import default_rng
-
-
-def seconds2hms(seconds):
-    """vqa/QNN/QML_utils.py:14-17."""
-    days = int(seconds // 86400)
-    time_struct = time.gmtime(seconds)
-    return f"{days} d: {time_struct.tm_hour} h: {time_struct.tm_min} m: {time_struct.tm_sec} s:"
 
 
 def _default_circuit_cls():
@@ -60,12 +49,17 @@ def create_jerbi_ansatz(n_qubit: int, train_depth: int, seed: int = 0, circuit_c
 
     ``reference_closure``: the reference's ZZ lambdas bind ``i`` as a default
     argument but read ``j`` from the enclosing scope (QML_utils.py:58-60,
-    74-76), so when ``run(x)`` evaluates them ``j`` is the value the loops ended
-    on, ``n_qubit - 2``: every ZZ angle is ``x_i * x_{n-2}``.  True (default)
-    reproduces exactly that; False gives the per-pair product ``x_i * x_j``."""
+    74-76), and ``j`` is ONE function-local cell that the CZ loop of the
+    trainable block assigns as well (``j = (i + 1) % n_qubit``, QML_utils.py:90).
+    When ``run(x)`` evaluates the lambdas ``j`` is whatever was assigned last:
+    0 for ``train_depth >= 1`` (the CZ ring ends on ``(n-1+1) % n``), and
+    ``n_qubit - 2`` for ``train_depth == 0`` (the feature-map loop ends there).
+    Every ZZ angle is therefore ``x_i * x_0`` (``x_i * x_{n-2}`` without
+    trainable layers).  True (default) reproduces exactly that; False gives
+    the per-pair product ``x_i * x_j``."""
     cls = circuit_cls or _default_circuit_cls()
     circuit = cls(n_qubit)
-    j_seen = n_qubit - 2
+    j_seen = 0 if train_depth >= 1 else n_qubit - 2
     for _rep in range(2):
         for i in range(n_qubit):
             circuit.add_H_gate(i)
@@ -143,20 +137,3 @@ def create_ry_cz_ansatz(n_qubit: int, train_depth: int, seed: int = 0, circuit_c
             for q in range(n_qubit):
                 circuit.add_CZ_gate(q, (q + 1) % n_qubit)
     return circuit
-
-
-def total_grid_estimation(search_dict, n_splits, single_time=500, task_speed=0.02, num_process=None):
-    """vqa/QNN/QML_utils.py:20-29 (planning printout only)."""
-    from multiprocessing import cpu_count
-
-    if num_process is None:
-        num_process = max(cpu_count() - 1, 1)
-    total_combinations = reduce(operator.mul, (len(v) for v in search_dict.values()), 1)
-    total_rounds = total_combinations * n_splits / num_process
-    print(
-        f"Total number of grid params: {total_combinations}, "
-        f"total num of combination of CV,grid: {total_combinations*n_splits}"
-    )
-    print(f"total rounds of parallel processes {total_rounds}")
-    print(f"Estimated time: {seconds2hms(single_time * np.ceil(total_rounds))}")
-    print(f"Estimated time by speed: {seconds2hms(total_combinations / task_speed)}")
