@@ -11,9 +11,15 @@ and applies the reference's per-sample statistics to the returned matrix of
 exact expectation values with NumPy:
 
 * exact mode (``min_approx_shots == -10``), CLT mode (``n >= min_approx_shots``:
-  ``E + randn() * sqrt((1 - E^2) / n)``) and finite-shot mode (binomial draws on
-  the exact Z0 distribution; the reference draws basis states with qulacs'
-  private generator, so this mode agrees in distribution only);
+  ``E + randn() * sqrt((1 - E^2) / n)``) and finite-shot mode (the reference draws
+  basis states with qulacs' private generator, so this mode agrees with it in
+  distribution only).  Finite-shot draws come in two flavours, ``shot_draws``:
+  ``"binomial"`` (default; one binomial per sample on the exact Z0 distribution) and
+  ``"per_shot"`` (every shot drawn by itself, per sample in the reference's call order, as
+  ``numpy.random.choice(4, size=n, p=<distribution of qubits 0, 1>)``: the global generator
+  is then consumed exactly as by the reference's per-sample code running on a
+  ``state.sampling`` that draws that way, which is how tests/golden/host_layer.json -- recorded
+  from the reference's own classes -- is replayed number by number);
 * the NumPy global generator is consumed in the reference's order: unshifted
   evaluation first (sample-major), then per parameter the +shift samples and
   the -shift samples;
@@ -57,7 +63,10 @@ class myQNN_base:
     def __init__(self, n_qubits, learning_circuit, x_train=None, y_train=None, x_test=None, y_test=None,
                  min_approx_shots=-1, setting_dict=None, id_string="QNN", file_id=None, obs=None,
                  shot_time=1.0, per_circuit_overhead=0.0, communication_overhead=0.0,
-                 max_sub_nqubits_sampling_aft_partial_tr=6, device_statistics=False):
+                 max_sub_nqubits_sampling_aft_partial_tr=6, device_statistics=False, shot_draws="binomial"):
+        if shot_draws not in ("binomial", "per_shot"):
+            raise ValueError("shot_draws must be 'binomial' or 'per_shot'")
+        self.shot_draws = shot_draws
         self.circuit = learning_circuit
         # True: in pure CLT mode the gradient oracle draws its normal deviates on the GPU
         # (torch generator seeded from NumPy's) and returns only the gradient; same
@@ -240,21 +249,58 @@ class myQNN_base:
             self._handles[which] = self.circuit.upload_inputs(x)
         return self._handles[which]
 
-    def _expect_all(self, params, x_list=None, which=None, idx=None):
-        """Exact <Z0> for each sample: an explicit x_list, or rows idx of a resident set."""
+    # finite-shot draws of this class read the readout distribution, not the model observable
+    # (they coincide for the regressor: both are Z0)
+    _sample_from_marginal = False
+
+    def _marg_bits(self):
+        return min(2, self.n_qubits)
+
+    @staticmethod
+    def _pad4(m):
+        """Distribution of qubits (0, 1) as 4 columns (a 1-qubit register has 2)."""
+        m = _np(m)
+        if m.shape[-1] == 4:
+            return m
+        out = np.zeros(m.shape[:-1] + (4,))
+        out[..., :m.shape[-1]] = m
+        return out
+
+    def _may_sample(self, n_s, min_approx):
+        """Whether any estimate of a call is drawn shot by shot (myQNNs_base.py:806, 883)."""
+        if min_approx == -10:
+            return False
+        n_s = np.asarray(n_s)
+        return bool(min_approx < 0 or (n_s.size and n_s.min() < min_approx))
+
+    def _wants_marginal(self, n_s, min_approx, no_power=False):
+        sampling = self._may_sample(n_s, min_approx) or (no_power and min_approx == -10)
+        return sampling and (self.shot_draws == "per_shot" or self._sample_from_marginal)
+
+    def _expect_all(self, params, x_list=None, which=None, idx=None, with_marginal=False):
+        """Exact <Z0> for each sample: an explicit x_list, or rows idx of a resident set.
+        with_marginal: also the distribution of qubits (0, 1), [B, 4]."""
         theta = np.asarray(params[:self.n_c_params], dtype=np.float64)
+        mb = self._marg_bits() if with_marginal else 0
         if x_list is not None:
             inputs = self.circuit.upload_inputs(np.asarray(x_list))
-            e, _ = self.circuit.eval_batch(theta, inputs, obs_list=self._obs_list())
+            e, m = self.circuit.eval_batch(theta, inputs, obs_list=self._obs_list(), n_marg_bits=mb)
         else:
-            e, _ = self.circuit.eval_batch(theta, self._handle(which), sample_idx=None if idx is None else np.asarray(idx, np.int32),
-                                           obs_list=self._obs_list())
+            e, m = self.circuit.eval_batch(theta, self._handle(which), sample_idx=None if idx is None else np.asarray(idx, np.int32),
+                                           obs_list=self._obs_list(), n_marg_bits=mb)
+        if with_marginal:
+            return _np(e)[:, 0], self._pad4(m)
         return _np(e)[:, 0]
 
-    def _psr_all(self, params, idx, keep_on_device=False):
-        """Exact <Z0> of the 2P+1 parameter-shift instances of each selected training sample: [B, 2P+1]."""
+    def _psr_all(self, params, idx, keep_on_device=False, with_marginal=False):
+        """Exact <Z0> of the 2P+1 parameter-shift instances of each selected training sample: [B, 2P+1].
+        with_marginal: also the distribution of qubits (0, 1) of every instance, [B, 2P+1, 4]."""
         theta = np.asarray(params[:self.n_c_params], dtype=np.float64)
-        e, _ = self.circuit.psr_full(theta, self._handle("train"), sel=np.asarray(idx, np.int32), obs_list=self._obs_list())
+        mb = self._marg_bits() if with_marginal else 0
+        e, m = self.circuit.psr_full(theta, self._handle("train"), sel=np.asarray(idx, np.int32), obs_list=self._obs_list(),
+                                     n_marg_bits=mb)
+        if with_marginal:
+            return _np(e)[:, :, 0], self._pad4(m)
         return e[:, :, 0] if keep_on_device else _np(e)[:, :, 0]
 
     # ---- per-sample statistics (myQNNs_base.py:715-738, 799-905) ----------------------
@@ -274,9 +320,15 @@ class myQNN_base:
                        if unbiased else M ** 4)
         return out[:max(order, 1)]
 
-    def _draw_means(self, exact, n_s, min_approx):
-        """Estimated <Z0> of each sample from its exact value: CLT noise or binomial
-        sampling per sample, global NumPy generator, sample order."""
+    @staticmethod
+    def _shots_low2(marg_row, n):
+        """n shots of qubits (0, 1), one uniform each, from the global generator."""
+        return np.random.choice(4, size=int(n), p=marg_row)
+
+    def _draw_means(self, exact, n_s, min_approx, marg=None):
+        """Estimated <Z0> of each sample from its exact value: CLT noise or finite-shot
+        sampling per sample, global NumPy generator, sample order.  marg [B, 4]: the
+        distribution of qubits (0, 1), which the finite-shot draws read when given."""
         exact = np.asarray(exact, dtype=float)
         n_s = np.asarray(n_s)
         B = len(exact)
@@ -288,7 +340,16 @@ class myQNN_base:
             if not sampled.any():
                 return exact + np.random.randn(B) * np.sqrt(var / n_s)
             est = np.empty(B)
-            p_minus = np.clip(0.5 * (1.0 - exact), 0.0, 1.0)
+            if self.shot_draws == "per_shot":
+                if marg is None:
+                    raise ValueError("per-shot draws need the readout distribution")
+                for j in range(B):
+                    if sampled[j]:
+                        est[j] = np.mean((-1) ** (self._shots_low2(marg[j], n_s[j]) % 2))    # myQNNs_base.py:725-733
+                    else:
+                        est[j] = exact[j] + np.random.randn() * np.sqrt(var[j] / n_s[j])
+                return est
+            p_minus = np.clip(0.5 * (1.0 - exact) if marg is None else marg[:, 1] + marg[:, 3], 0.0, 1.0)
             if sampled.all():
                 k = np.random.binomial(n_s.astype(np.int64), p_minus)
                 return (n_s - 2.0 * k) / n_s
@@ -299,7 +360,7 @@ class myQNN_base:
                     est[j] = exact[j] + np.random.randn() * np.sqrt(var[j] / n_s[j])
             return est
 
-    def _estimate(self, exact, n_s, min_approx, order=4, Return_var=False, unbiased=False, no_power=False):
+    def _estimate(self, exact, n_s, min_approx, order=4, Return_var=False, unbiased=False, no_power=False, marg=None):
         """Batched _single_state_hybrid_sampler[_power] (myQNNs_base.py:799-818, 867-905)."""
         exact = np.asarray(exact, dtype=float)
         n_s = np.asarray(n_s)
@@ -308,7 +369,7 @@ class myQNN_base:
             self.call_counter[0] += len(exact)
             EO = [exact ** k for k in range(1, order + 1)]
             return (EO, 1.0 - exact ** 2) if Return_var else EO
-        M = self._draw_means(exact, n_s, min_approx)
+        M = self._draw_means(exact, n_s, min_approx, marg)
         nf = n_s.astype(float)
         with np.errstate(divide="ignore", invalid="ignore"):
             var = nf / (nf - 1.0) * (1.0 - M ** 2)
@@ -320,8 +381,14 @@ class myQNN_base:
     # the reference's per-call names, batched ------------------------------------------
     def _sample_obs_data_by_data(self, params, x_eval, n_s_list, min_approx, order=4, Return_var=False, unbiased=False):
         """myQNNs_base.py:1100-1125 for an explicit list of samples."""
-        exact = self._expect_all(params, x_list=x_eval)
-        return self._estimate(exact, n_s_list, min_approx, order=order, Return_var=Return_var, unbiased=unbiased)
+        exact, marg = self._expect_maybe_marg(params, n_s_list, min_approx, x_list=x_eval)
+        return self._estimate(exact, n_s_list, min_approx, order=order, Return_var=Return_var, unbiased=unbiased, marg=marg)
+
+    def _expect_maybe_marg(self, params, n_s, min_approx, no_power=False, **where):
+        """(exact, marg or None): the readout distribution rides along when draws need it."""
+        if self._wants_marginal(n_s, min_approx, no_power):
+            return self._expect_all(params, with_marginal=True, **where)
+        return self._expect_all(params, **where), None
 
     def _sample_predict_scaled(self, x_eval, n_s_list, params=None, min_approx=None, Return_var=False):
         """myQNNs_base.py:1044-1070."""
@@ -329,12 +396,12 @@ class myQNN_base:
             min_approx = self.min_approx_shots
         if params is None:
             params = self.model_params
-        exact = self._expect_all(params, x_list=x_eval)
+        exact, marg = self._expect_maybe_marg(params, n_s_list, min_approx, no_power=True, x_list=x_eval)
         w = params[-1]
         if Return_var:
-            M, var = self._estimate(exact, n_s_list, min_approx, Return_var=True, no_power=True)
+            M, var = self._estimate(exact, n_s_list, min_approx, Return_var=True, no_power=True, marg=marg)
             return w * M, var * w ** 2
-        return self._estimate(exact, n_s_list, min_approx, no_power=True) * w
+        return self._estimate(exact, n_s_list, min_approx, no_power=True, marg=marg) * w
 
     def _sample_predict_no_scale(self, x_eval, n_s_list, params=None, min_approx=None, Return_var=False):
         """myQNNs_base.py:1072-1097."""
@@ -342,8 +409,8 @@ class myQNN_base:
             min_approx = self.min_approx_shots
         if params is None:
             params = self.model_params
-        exact = self._expect_all(params, x_list=x_eval)
-        return self._estimate(exact, n_s_list, min_approx, Return_var=Return_var, no_power=True)
+        exact, marg = self._expect_maybe_marg(params, n_s_list, min_approx, no_power=True, x_list=x_eval)
+        return self._estimate(exact, n_s_list, min_approx, Return_var=Return_var, no_power=True, marg=marg)
 
     def sample_predict(self, x_eval, n_s_list, params=None, min_approx=None, Return_var=False):
         return self._sample_predict_scaled(x_eval, n_s_list, params, min_approx, Return_var)
@@ -529,20 +596,29 @@ class myQNN_base:
             g = self._grad_on_device(params, n_shots_list, wt_dist, eval_ind, y_eval, min_approx)
             if g is not None:
                 return g
-        E = self._psr_all(params, eval_ind)
+        E, Mg = self._psr_maybe_marg(params, eval_ind, n_shots_list, wt_dist, min_approx)
         n_shots_data_list = np.floor(n_shots_list[-1] * wt_dist).astype(int)
         w = params[-1]
-        EX0 = self._estimate(E[:, 0], n_shots_data_list, min_approx, order=4, unbiased=True)
+        EX0 = self._estimate(E[:, 0], n_shots_data_list, min_approx, order=4, unbiased=True, marg=Mg(0))
         EX0_list = EX0[0]
         self.cache_train_pred = w * EX0_list
         self.cache_y_train_eval = y_eval
         grad[-1] = np.mean(2.0 * (-y_eval * EX0_list + w * EX0[1]))
         for i in range(len(params) - 1):
             n_shots_data_list = np.floor(n_shots_list[i] * wt_dist).astype(int)
-            EXp = self._estimate(E[:, 1 + 2 * i], n_shots_data_list, min_approx, order=2, unbiased=True)
-            EXm = self._estimate(E[:, 2 + 2 * i], n_shots_data_list, min_approx, order=2, unbiased=True)
+            EXp = self._estimate(E[:, 1 + 2 * i], n_shots_data_list, min_approx, order=2, unbiased=True, marg=Mg(1 + 2 * i))
+            EXm = self._estimate(E[:, 2 + 2 * i], n_shots_data_list, min_approx, order=2, unbiased=True, marg=Mg(2 + 2 * i))
             grad[i] = np.mean((w * EX0_list - y_eval) * w * (EXp[0] - EXm[0]))
         return grad
+
+    def _psr_maybe_marg(self, params, eval_ind, n_shots_list, wt_dist, min_approx, force=False):
+        """(E [B, 2P+1], column -> readout distribution [B, 4] or None) of a sweep: the
+        distributions ride along when some estimate of the call is drawn shot by shot."""
+        n_min = np.floor(np.min(n_shots_list) * (np.min(wt_dist) if len(wt_dist) else 1.0))
+        if (force or self._may_sample(n_min, min_approx)) and (self.shot_draws == "per_shot" or self._sample_from_marginal):
+            E, M = self._psr_all(params, eval_ind, with_marginal=True)
+            return E, lambda k: M[:, k]
+        return self._psr_all(params, eval_ind), lambda k: None
 
     def _exact_grad(self, params, eval_ind, y_eval):
         """MSE_grad_eval in exact mode (min_approx_shots = -10; myQNNs_base.py:874-882 makes every
@@ -751,8 +827,8 @@ class myQNN_base:
         """myQNNs_base.py:1397-1419."""
         min_approx, wt_dist, eval_ind, y_eval = self._batch_setup(mini_batch_size, option_min_approx, option_weight)
         n_shots_data_list = np.floor(n_shots * wt_dist).astype(int)
-        exact = self._expect_all(params, which="train", idx=eval_ind)
-        EX0 = self._estimate(exact, n_shots_data_list, min_approx, order=2, unbiased=True)
+        exact, marg = self._expect_maybe_marg(params, n_shots_data_list, min_approx, which="train", idx=eval_ind)
+        EX0 = self._estimate(exact, n_shots_data_list, min_approx, order=2, unbiased=True, marg=marg)
         w = params[-1]
         return np.mean(w ** 2 * EX0[1] - 2.0 * w * y_eval * EX0[0] + np.square(y_eval))
 
@@ -772,18 +848,19 @@ class myQNN_base:
             if out is not None:
                 return out
         grad_data_list = np.zeros((len(params), len(eval_ind)))
-        E = self._psr_all(params, eval_ind)
+        debug = min_approx == -10
+        E, Mg = self._psr_maybe_marg(params, eval_ind, n_shots_list, wt_dist, min_approx, force=debug)
         n0 = n_shots_list[-1]
         n_shots0 = np.max(n_shots_list) if Max_n_shots0 else n_shots_list[-1]
         n_shots_data_list = np.floor(n_shots0 * wt_dist).astype(int)
         w = params[-1]
-        debug = min_approx == -10
         if debug:
             EX0pow_exact, var_0_exact = self._estimate(E[:, 0], n_shots_data_list, -10, order=4, Return_var=True, unbiased=True)
-            EX0pow, var_0 = self._estimate(E[:, 0], n_shots_data_list, -1, order=4, Return_var=True, unbiased=True)
+            EX0pow, var_0 = self._estimate(E[:, 0], n_shots_data_list, -1, order=4, Return_var=True, unbiased=True, marg=Mg(0))
             grad_data_exact = 2.0 * (-y_eval * EX0pow_exact[0] + w * EX0pow_exact[1])
         else:
-            EX0pow, var_0 = self._estimate(E[:, 0], n_shots_data_list, min_approx, order=4, Return_var=True, unbiased=True)
+            EX0pow, var_0 = self._estimate(E[:, 0], n_shots_data_list, min_approx, order=4, Return_var=True, unbiased=True,
+                                           marg=Mg(0))
         EX0_list = EX0pow[0]
         self.cache_train_pred = w * EX0_list
         self.cache_y_train_eval = y_eval
@@ -805,12 +882,14 @@ class myQNN_base:
             if debug:
                 EXp_exact, var_p_exact = self._estimate(Ep, n_shots_data_list, -10, order=2, Return_var=True, unbiased=True)
                 EXm_exact, var_m_exact = self._estimate(Em, n_shots_data_list, -10, order=2, Return_var=True, unbiased=True)
-                EXp, var_p = self._estimate(Ep, n_shots_data_list, -1, order=2, Return_var=True, unbiased=True)
-                EXm, var_m = self._estimate(Em, n_shots_data_list, -1, order=2, Return_var=True, unbiased=True)
+                EXp, var_p = self._estimate(Ep, n_shots_data_list, -1, order=2, Return_var=True, unbiased=True, marg=Mg(1 + 2 * i))
+                EXm, var_m = self._estimate(Em, n_shots_data_list, -1, order=2, Return_var=True, unbiased=True, marg=Mg(2 + 2 * i))
                 grad_data_exact = (w * EX0pow_exact[0] - y_eval) * w * (EXp_exact[0] - EXm_exact[0])
             else:
-                EXp, var_p = self._estimate(Ep, n_shots_data_list, min_approx, order=2, Return_var=True, unbiased=True)
-                EXm, var_m = self._estimate(Em, n_shots_data_list, min_approx, order=2, Return_var=True, unbiased=True)
+                EXp, var_p = self._estimate(Ep, n_shots_data_list, min_approx, order=2, Return_var=True, unbiased=True,
+                                            marg=Mg(1 + 2 * i))
+                EXm, var_m = self._estimate(Em, n_shots_data_list, min_approx, order=2, Return_var=True, unbiased=True,
+                                            marg=Mg(2 + 2 * i))
             grad_data_list[i] = (w * EX0_list - y_eval) * w * (EXp[0] - EXm[0])
             grad[i] = np.mean(grad_data_list[i])
             if debug:
@@ -830,15 +909,18 @@ class myQNN_base:
         return {"grad": grad, "gvar_list_EV": gvar_list_EV, "gvar_list_EVi": gvar_list_EVi,
                 "gvar_list_EV0": gvar_list_EV0, "gvar_list_b": gvar_list_b, "grad_data_list": grad_data_list}
 
-    def _outcomes(self, exact, n_s):
+    def _outcomes(self, exact, n_s, marg=None):
         """Raw +-1 outcome arrays (one per sample) drawn from the exact Z0 distribution
         (stands in for _sample_outcomes_sum_Z_all_data, myQNNs_base.py:749-765)."""
         self.circuit_counter[0] += len(exact)
         self.call_counter[0] += len(exact)
         self.shots_counter[0] += int(np.sum(n_s))
         out = []
-        for e, n in zip(exact, n_s):
-            out.append(np.where(np.random.random(int(n)) < 0.5 * (1.0 - e), -1, 1))
+        for j, (e, n) in enumerate(zip(exact, n_s)):
+            if self.shot_draws == "per_shot":
+                out.append((-1) ** (self._shots_low2(marg[j], n) % 2))
+            else:
+                out.append(np.where(np.random.random(int(n)) < 0.5 * (1.0 - e), -1, 1))
         return out, np.array([o.sum() for o in out], dtype=float)
 
     def MSE_iEval_iRandom(self, params, n_shots_list, option_weight=None):
@@ -853,6 +935,7 @@ class myQNN_base:
         w = params[-1]
         M_tot = self.num_train_data
         theta = np.asarray(params[:self.n_c_params], dtype=np.float64)
+        per_shot = self.shot_draws == "per_shot"
         for i in range(len(params)):
             n_shots_data_list = np.random.multinomial(n_shots_list[i], wt_dist)
             sel = np.nonzero(n_shots_data_list != 0)[0].astype(np.int32)
@@ -861,8 +944,9 @@ class myQNN_base:
             n = n_shots_list[i]
             if i == len(params) - 1:
                 n_shots_eval = n_shots_eval * 2
-                exact = self._expect_all(params, which="train", idx=sel)
-                outcomes0, outsum = self._outcomes(exact, n_shots_eval)
+                exact, marg = self._expect_all(params, which="train", idx=sel, with_marginal=True) if per_shot \
+                    else (self._expect_all(params, which="train", idx=sel), None)
+                outcomes0, outsum = self._outcomes(exact, n_shots_eval, marg)
                 grad[i] = np.sum(w * (outsum ** 2 - n_shots_eval) / (2 * n * (n - 1) / M_tot + n) - y_eval * outsum / n)
                 gvar_list[i] = self._direct_sample_MSEgrad_varUB_whole(y_eval, outcomes0, w=w, Scale_para=True)
             else:
@@ -870,12 +954,13 @@ class myQNN_base:
                 si = np.tile(sel, 3)
                 sp = np.concatenate([np.full(E, -1), np.full(E, i), np.full(E, i)]).astype(np.int32)
                 sv = np.concatenate([np.zeros(E), np.full(E, 0.5 * np.pi), np.full(E, -0.5 * np.pi)])
-                e, _ = self.circuit.eval_batch(theta, self._handle("train"), sample_idx=si, shift_param=sp, shift_val=sv,
-                                               obs_list=self._obs_list())
+                e, m = self.circuit.eval_batch(theta, self._handle("train"), sample_idx=si, shift_param=sp, shift_val=sv,
+                                               obs_list=self._obs_list(), n_marg_bits=self._marg_bits() if per_shot else 0)
                 e = _np(e)[:, 0]
-                outcomes0, outsum0 = self._outcomes(e[:E], n_shots_eval)
-                outcomes_p, outsum_p = self._outcomes(e[E:2 * E], n_shots_eval)
-                outcomes_m, outsum_m = self._outcomes(e[2 * E:], n_shots_eval)
+                m = self._pad4(m) if per_shot else [None] * (3 * E)
+                outcomes0, outsum0 = self._outcomes(e[:E], n_shots_eval, m[:E])
+                outcomes_p, outsum_p = self._outcomes(e[E:2 * E], n_shots_eval, m[E:2 * E])
+                outcomes_m, outsum_m = self._outcomes(e[2 * E:], n_shots_eval, m[2 * E:])
                 grad[i] = np.sum((w * outsum0 / (n + n * (n - 1) / M_tot) - y_eval / n) * (outsum_p - outsum_m) * w)
                 gvar_list[i] = self._direct_sample_MSEgrad_varUB_whole(y_eval, outcomes0, w=w, Scale_para=False,
                                                                        outcomes_whole_p=outcomes_p, outcomes_whole_m=outcomes_m)

@@ -37,7 +37,7 @@ class myQNN_classifier(myQNN_base):
                  min_approx_shots=-1, setting_dict=None, id_string="QNN", file_id=None, obs=None, num_classes=3,
                  shot_time=1.0, per_circuit_overhead=0.0, communication_overhead=0.0,
                  max_sub_nqubits_sampling_aft_partial_tr=6, partial_MSE=False, eps=0.0, class_unbias=True,
-                 noisy=False, **unused):
+                 noisy=False, device_statistics=False, shot_draws="binomial", **unused):
         if noisy:
             raise NotImplementedError("noisy circuits / error mitigation are outside this backend")
         if num_classes != 3:
@@ -49,7 +49,8 @@ class myQNN_classifier(myQNN_base):
         self._class_obs = None
         super().__init__(n_qubits, learning_circuit, x_train, y_train, x_test, y_test, min_approx_shots, setting_dict,
                          id_string, file_id, None, shot_time, per_circuit_overhead, communication_overhead,
-                         max_sub_nqubits_sampling_aft_partial_tr)
+                         max_sub_nqubits_sampling_aft_partial_tr, device_statistics=device_statistics,
+                         shot_draws=shot_draws)
         self.n_params = self.n_c_params  # no re-normalisation coefficient
 
     # ---- data ---------------------------------------------------------------------
@@ -93,6 +94,11 @@ class myQNN_classifier(myQNN_base):
         self.partial_MSE = partial_MSE
         self._eps = eps
         super().compile(*args, **kwargs)
+
+    # the inherited Z0 estimators (MSE_loss_eval) evaluate this class's default observable
+    # (Z0 Z1, myQNNs_classifier.py:282-293) in their exact / CLT branches but read qubit 0 of the
+    # drawn basis states in their finite-shot branch (myQNNs_classifier.py:549-572)
+    _sample_from_marginal = True
 
     def _default_obs(self):
         """myQNNs_classifier.py:282-293."""
@@ -212,6 +218,34 @@ class myQNN_classifier(myQNN_base):
             return [MSE, self.exact_MSE(params, which="train", ret_prediction=False)]
         return (MSE, y_pred_test) if ret_prediction else MSE
 
+    def exact_MAE(self, params, which="test", ret_both=False, log_evol=False, partial_MSE=False, ret_prediction=False):
+        """myQNNs_classifier.py:494-533: despite its name the same squared error as exact_MSE, with
+        plain argmax predictions; the train half of ret_both comes from exact_MSE (523-527)."""
+        if ret_both:
+            which = "test"
+        if which == "train":
+            p = self._exact_probs(params, which="train").astype(float)
+            y_pred = np.argmax(p, axis=1) if ret_prediction else None
+            if partial_MSE:
+                p = p * self.y_train_1hot
+            MSE = np.sum(np.square(p - self.y_train_1hot)) / len(self.y_train_1hot)
+            if log_evol:
+                self.exact_cost_evol.append(self.exact_MSE(params, which="test"))
+            return (MSE, y_pred) if ret_prediction else MSE
+        p = self._exact_probs(params, which="test").astype(float)
+        y_pred_test = np.argmax(p, axis=1) if ret_prediction else None
+        if partial_MSE:
+            p = p * self.y_test_1hot
+        MSE = np.sum(np.square(p - self.y_test_1hot)) / len(self.y_test_1hot)
+        if log_evol:
+            self.exact_cost_evol.append(MSE)
+        if ret_both:
+            if ret_prediction:
+                MSE_train, y_pred_train = self.exact_MSE(params, which="train", ret_prediction=True)
+                return [MSE, MSE_train], {"train": y_pred_train, "test": y_pred_test}
+            return [MSE, self.exact_MSE(params, which="train", ret_prediction=False)]
+        return (MSE, y_pred_test) if ret_prediction else MSE
+
     def exact_predict_error_and_MSE(self, params, loss="MSE", eps=None):
         """myQNNs_classifier.py:536-547."""
         if eps is None:
@@ -241,6 +275,9 @@ class myQNN_classifier(myQNN_base):
         self.circuit_counter[0] += B
         self.call_counter[0] += B
         self.shots_counter[0] += int(n_s.sum())
+        if self.shot_draws == "per_shot":
+            return np.array([np.bincount(self._class_outcomes(marg[j], n_s[j]), minlength=3)[:3] for j in range(B)],
+                            dtype=float).reshape(B, 3)
         k = np.zeros((B, 4), dtype=np.int64)
         left = n_s.copy()
         rest = np.ones(B)
@@ -256,6 +293,17 @@ class myQNN_classifier(myQNN_base):
             b = np.random.binomial(k[:, 3] - a, 0.5)
             return np.stack([k[:, 0] + a, k[:, 1] + b, k[:, 2] + (k[:, 3] - a - b)], axis=1).astype(float)
         return np.stack([k[:, 0] + k[:, 3], k[:, 1], k[:, 2]], axis=1).astype(float)
+
+    def _class_outcomes(self, marg_row, n):
+        """Class index of each of n shots of one state, drawn one by one
+        (myQNNs_classifier.py:613-619, 640-647): the readout of qubits (0, 1), then outcome 3 dealt
+        to a uniformly random class (class_unbias) or folded onto class 0."""
+        outcomes = self._shots_low2(marg_row, n)
+        if self.class_unbias:
+            idx3 = np.where(outcomes == 3)[0]
+            outcomes[idx3] = np.random.choice([0, 1, 2], size=len(idx3))
+            return outcomes
+        return outcomes % 3
 
     @staticmethod
     def _count_stats(count, n):
@@ -409,12 +457,15 @@ class myQNN_classifier(myQNN_base):
         return {"grad": grad, "gvar_list_EV": gvar_list_EV, "gvar_list_EVi": z.copy(), "gvar_list_EV0": z.copy(),
                 "gvar_list_b": z.copy(), "grad_data_list": grad_data_list}
 
-    def _success_outcomes(self, p_success, n_s):
+    def _success_outcomes(self, p_success, n_s, marg=None, y_eval=None):
         """0/1 outcome arrays of 'the true class was read' (myQNNs_classifier.py:818-822)."""
         self.circuit_counter[0] += len(n_s)
         self.call_counter[0] += len(n_s)
         self.shots_counter[0] += int(np.sum(n_s))
-        out = [(np.random.random(int(n)) < p).astype(float) for p, n in zip(p_success, n_s)]
+        if self.shot_draws == "per_shot":
+            out = [(self._class_outcomes(m, n) == int(c)).astype(float) for m, n, c in zip(marg, n_s, y_eval)]
+        else:
+            out = [(np.random.random(int(n)) < p).astype(float) for p, n in zip(p_success, n_s)]
         return out, np.array([o.sum() for o in out])
 
     def MSE_iEval_iRandom(self, params, n_shots_list, option_weight=None, partial_MSE=True):
@@ -437,12 +488,14 @@ class myQNN_classifier(myQNN_base):
             si = np.tile(sel, 3)
             sp = np.concatenate([np.full(E, -1), np.full(E, i), np.full(E, i)]).astype(np.int32)
             sv = np.concatenate([np.zeros(E), np.full(E, 0.5 * np.pi), np.full(E, -0.5 * np.pi)])
-            e, _ = self.circuit.eval_batch(theta, self._handle("train"), sample_idx=si, shift_param=sp, shift_val=sv,
-                                           obs_list=self.class_observables())
+            per_shot = self.shot_draws == "per_shot"
+            e, m = self.circuit.eval_batch(theta, self._handle("train"), sample_idx=si, shift_param=sp, shift_val=sv,
+                                           obs_list=self.class_observables(), n_marg_bits=2 if per_shot else 0)
             p = np.clip(_np(e)[np.arange(3 * E), np.tile(np.asarray(y_eval, dtype=int), 3)], 0.0, 1.0)
-            out0, sum0 = self._success_outcomes(p[:E], n_eval)
-            outp, sump = self._success_outcomes(p[E:2 * E], n_eval)
-            outm, summ = self._success_outcomes(p[2 * E:], n_eval)
+            m = np.clip(_np(m), 0.0, 1.0) if per_shot else [None] * (3 * E)
+            out0, sum0 = self._success_outcomes(p[:E], n_eval, m[:E], y_eval)
+            outp, sump = self._success_outcomes(p[E:2 * E], n_eval, m[E:2 * E], y_eval)
+            outm, summ = self._success_outcomes(p[2 * E:], n_eval, m[2 * E:], y_eval)
             grad[i] = np.sum((sum0 / (1.0 + (n - 1) / M_tot) - 1.0) * (sump - summ) / n)
             g = (np.concatenate(out0) - 1.0) * (np.concatenate(outp) - np.concatenate(outm))
             gvar_list[i] = np.var(g, ddof=1)
@@ -496,6 +549,7 @@ class myQNN_classifier(myQNN_base):
     def CE_loss_eval(self):
         """Empty in the reference (myQNNs_classifier.py:1275-1276)."""
 
-    def MSE_loss_eval(self, *a, **k):
-        raise NotImplementedError("the reference's classifier has no sampled MSE loss of its own "
-                                  "(it inherits the regressor's Z0 estimator, which does not apply to class probabilities)")
+    # MSE_loss_eval: inherited from the regressor as in the reference (myQNNs_base.py:1397-1419 through
+    # myQNNs_classifier.py:48): a Z-readout estimator scaled by params[-1], which is a CIRCUIT parameter
+    # here -- not a loss of the class probabilities; kept so that the optimizers' 'loss' slot behaves
+    # as it does there.
