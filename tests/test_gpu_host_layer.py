@@ -184,7 +184,7 @@ def test_device_ieval_equals_host_algebra(second_order, max_n0):
     M = np.clip(E + rng.normal(size=E.shape) * 0.4, -1, 1)                     # any estimates will do
     cols = iter(range(E.shape[1]))
     orig = h._draw_means
-    h._draw_means = lambda exact, n_s, ma: (orig(exact, n_s, ma), M[:, next(cols)])[1]
+    h._draw_means = lambda exact, n_s, ma, marg=None: (orig(exact, n_s, ma, marg), M[:, next(cols)])[1]
     want = h.MSE_iEval(p, shots, mini_batch_size=N, option_min_approx=0, Max_n_shots0=max_n0, second_order=second_order)
     ma, wt, idx, y = g._batch_setup(N, 0, None)
     got = g._ieval_on_device(p, shots, wt, idx, y, 0, N, max_n0, second_order, _estimates=torch.from_numpy(M).cuda())
