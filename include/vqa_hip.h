@@ -181,10 +181,12 @@ int vqa_eval_batch_dev(vqa_circuit* c, int device, void* stream,
  * vqa/QNN/myQNNs_classifier.py:1116-1156).
  *
  * Sweeps (and every call served by the streaming engine, n >= 14) use a
- * workspace the library keeps per device and grows on demand: calls that
- * overlap in time on ONE device, from different threads or streams, race on
- * it.  Order them on one stream or synchronise between them; different
- * devices are independent.
+ * workspace the library keeps per device and grows on demand.  Calls on one
+ * device may come from different threads and streams: a call holds a
+ * per-device lock while it queues its work, and a call that takes the
+ * workspace makes its stream wait for the previous user's last kernel (an
+ * event), so such calls run one after the other on the GPU.  Different devices
+ * are independent.
  */
 int vqa_psr_full(vqa_circuit* c, int device,
                  const double* theta, const double* input_angles, int B,

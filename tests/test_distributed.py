@@ -106,3 +106,39 @@ def test_two_rank_vqe_gradient_shards_the_parameters():
         assert np.max(np.abs(grad - want["grad"])) < 1e-13
         assert np.max(np.abs(gvar - want["gvar_list"])) < 1e-13
         assert n_circ == 2 * v.n_params
+
+
+def vqe_noisy_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from test_vqe_target import make
+    v, p = make(n=5, d=2, min_approx=0)
+    v.group = dist.group.WORLD
+    np.random.seed(100 + rank)          # the ranks' generators differ on purpose
+    out = v.iEval(p, np.full(v.n_params, 100))
+    q.put((rank, out["grad"], out["gvar_list"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_vqe_noisy_gradients_agree():
+    """CLT mode with the parameters sharded: every rank must return the SAME noisy gradient (rank 0's
+    deviates are broadcast), equal to what one process seeded like rank 0 computes."""
+    from test_vqe_target import make
+    v, p = make(n=5, d=2, min_approx=0)
+    np.random.seed(100)
+    want = v.iEval(p, np.full(v.n_params, 100))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=vqe_noisy_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    got = sorted([q.get(timeout=120) for _ in procs], key=lambda g: g[0])
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    assert np.array_equal(got[0][1], got[1][1]) and np.array_equal(got[0][2], got[1][2])
+    assert np.max(np.abs(got[0][1] - want["grad"])) < 1e-12

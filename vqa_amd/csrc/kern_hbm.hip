@@ -1540,7 +1540,7 @@ int hbm_engine_run(const EvalCall& call) {
     const size_t o_hgate = cv.add(hl.pd.plan ? gate_buf_bytes(hl.pd.g) : 0);
     const size_t o_hmats = cv.add(hl.pd.plan ? hl.pd.mats_bytes(Cmax) : 0);
     void* ws = nullptr;
-    rc = workspace_get(call.device, cv.total, &ws);
+    rc = call_workspace(call, cv.total, &ws);
     if (rc) return rc;
     char* w = (char*)ws;
     double2* st = (double2*)(w + o_st);
@@ -1659,7 +1659,7 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
     const size_t o_hgate = cv.add(hl.pd.plan ? gate_buf_bytes(hl.pd.g) : 0);
     const size_t o_hmats = cv.add(hl.pd.plan ? hl.pd.mats_bytes(C) : 0);
     void* ws = nullptr;
-    rc = workspace_get(call.device, cv.total, &ws);
+    rc = call_workspace(call, cv.total, &ws);
     if (rc) return rc;
     char* w = (char*)ws;
     double2* st = (double2*)(w + o_st);
@@ -1770,7 +1770,7 @@ int hbm_engine_statevector(const EvalCall& call, double* d_out_state) {
     const size_t o_gate = cv.add(pd.plan ? gate_buf_bytes(pd.g) : 0);
     const size_t o_mats = cv.add(pd.plan ? pd.mats_bytes(1) : 0);
     void* ws = nullptr;
-    int rc = workspace_get(call.device, cv.total, &ws);
+    int rc = call_workspace(call, cv.total, &ws);
     if (rc) return rc;
     char* w = (char*)ws;
     if (pd.plan) {

@@ -1594,19 +1594,6 @@ int reg_engine_sweep(const EvalCall& call, const void* d_prog, const RegProgram&
     if (n_samples <= 0) return VQA_OK;
     RegArgs a = make_args(call, d_prog);
     a.E = n_samples;
-    // resident workgroups per CU: what LDS allows, and the register budget of the launch bounds for
-    // the one- and two-wave workgroups of 10 and 11 qubits (VQA_WAVES waves per SIMD)
-    const int by_regs = P.hdr.block <= 128 ? VQA_SMALL_WAVES * 4 / (P.hdr.block / 64) : 8;
-    const int per_cu = std::max<int>(1, std::min<int>(by_regs, (int)((160 * 1024) / std::max<size_t>(P.lds_bytes_psr, 1))));
-    // Few samples: the run list of a sample is cut into slices for different workgroups, each of
-    // which runs the unshifted circuit for its own checkpoints first (a single circuit, the VQE
-    // case, would otherwise keep one workgroup busy and the rest of the GPU idle).
-    const int64_t slots = (int64_t)256 * per_cu;
-    const int64_t n_runs_max = std::max(P.hdr.n_runs, 1);
-    const int split = (int)std::max<int64_t>(1, std::min<int64_t>(slots / n_samples, n_runs_max));
-    const int grid = (int)std::min<int64_t>((int64_t)n_samples * split, slots);
-    const size_t ck_bytes = (size_t)grid * (P.hdr.n_ddesc + 1) * ((size_t)16 << P.hdr.n);
-    const size_t rec_bytes = (size_t)grid * std::max(P.hdr.n_runs, 1) * sizeof(RunRec);
     // the runs of the parameters that can matter for this call's observables; the rows of the
     // others are copies of the unshifted row (filled in below)
     ConeInfo& cone = *call.cone;
@@ -1631,13 +1618,40 @@ int reg_engine_sweep(const EvalCall& call, const void* d_prog, const RegProgram&
     const std::vector<int32_t>& dead_list = call.param_mask ? m_dead : cone.dead_list;
     const int n_dead = (int)dead_list.size();
     const size_t n_live = live_runs.size();
-    const size_t live_bytes = ((n_live + (size_t)n_dead) * sizeof(int32_t) + 255) & ~(size_t)255;
+    // (each list starts on a 16-byte boundary: the allocation-free upload stores 16 bytes at a time)
+    const size_t live_part = (n_live * sizeof(int32_t) + 15) & ~(size_t)15;
+    const size_t live_bytes = (live_part + (size_t)n_dead * sizeof(int32_t) + 255) & ~(size_t)255;
+    // resident workgroups per CU: what LDS allows, and the register budget of the launch bounds for
+    // the one- and two-wave workgroups of 10 and 11 qubits (VQA_WAVES waves per SIMD)
+    const int by_regs = P.hdr.block <= 128 ? VQA_SMALL_WAVES * 4 / (P.hdr.block / 64) : 8;
+    const int per_cu = std::max<int>(1, std::min<int>(by_regs, (int)((160 * 1024) / std::max<size_t>(P.lds_bytes_psr, 1))));
+    // every workgroup of the launch owns an area of state images and run records; a call with a
+    // fixed region of working memory launches as many workgroups as the region holds areas for
+    // (workgroups draw samples from a counter, so any grid size completes the sweep)
+    const size_t wg_bytes = (size_t)(P.hdr.n_ddesc + 1) * ((size_t)16 << P.hdr.n) +
+                            (size_t)std::max(P.hdr.n_runs, 1) * sizeof(RunRec);
+    int64_t slots = (int64_t)256 * per_cu;
+    const size_t room = call_workspace_room(call);
+    if (room != SIZE_MAX) {
+        if (room < 256 + live_bytes + wg_bytes)
+            VQA_FAIL(VQA_EUNSUPPORTED, "this sweep needs %zu bytes of working memory per workgroup, the fixed region has %zu left",
+                     256 + live_bytes + wg_bytes, room);
+        slots = std::min<int64_t>(slots, (int64_t)((room - 256 - live_bytes) / wg_bytes));
+    }
+    // Few samples: the run list of a sample is cut into slices for different workgroups, each of
+    // which runs the unshifted circuit for its own checkpoints first (a single circuit, the VQE
+    // case, would otherwise keep one workgroup busy and the rest of the GPU idle).
+    const int64_t n_runs_max = std::max(P.hdr.n_runs, 1);
+    const int split = (int)std::max<int64_t>(1, std::min<int64_t>(slots / n_samples, n_runs_max));
+    const int grid = (int)std::min<int64_t>((int64_t)n_samples * split, slots);
+    const size_t ck_bytes = (size_t)grid * (P.hdr.n_ddesc + 1) * ((size_t)16 << P.hdr.n);
+    const size_t rec_bytes = (size_t)grid * std::max(P.hdr.n_runs, 1) * sizeof(RunRec);
     void* ws = nullptr;
-    rc = workspace_get(call.device, 256 + live_bytes + ck_bytes + rec_bytes, &ws);
+    rc = call_workspace(call, 256 + live_bytes + ck_bytes + rec_bytes, &ws);
     if (rc) return rc;
     a.next = (unsigned*)ws;
     int32_t* d_live = (int32_t*)((char*)ws + 256);
-    int32_t* d_dead = d_live + n_live;
+    int32_t* d_dead = (int32_t*)((char*)ws + 256 + live_part);
     a.ckpt = (double2*)((char*)ws + 256 + live_bytes);
     a.recs = (RunRec*)((char*)ws + 256 + live_bytes + ck_bytes);
     a.live = d_live;
@@ -1645,11 +1659,8 @@ int reg_engine_sweep(const EvalCall& call, const void* d_prog, const RegProgram&
     a.split = (int)std::max<size_t>(1, std::min<size_t>((size_t)split, n_live));
     VQA_HIP(hipMemsetAsync(a.next, 0, 256, call.stream));
     // (the lists live as long as the circuit: the asynchronous copies may read them after this returns)
-    if (n_live)
-        VQA_HIP(hipMemcpyAsync(d_live, live_runs.data(), n_live * sizeof(int32_t), hipMemcpyHostToDevice, call.stream));
-    if (n_dead)
-        VQA_HIP(hipMemcpyAsync(d_dead, dead_list.data(), (size_t)n_dead * sizeof(int32_t), hipMemcpyHostToDevice,
-                               call.stream));
+    if (n_live && (rc = call_upload(call, d_live, live_runs.data(), n_live * sizeof(int32_t)))) return rc;
+    if (n_dead && (rc = call_upload(call, d_dead, dead_list.data(), (size_t)n_dead * sizeof(int32_t)))) return rc;
     const void* fn = P.hdr.block == 64 ? (const void*)k_reg_psr<64>
                    : P.hdr.block == 128 ? (const void*)k_reg_psr<128>
                    : P.hdr.block == 256 ? (const void*)k_reg_psr<256>
@@ -1734,15 +1745,14 @@ int reg_engine_group(const EvalCall& call, const void* d_prog, const RegProgram&
     const std::vector<int32_t>& dead_list = call.param_mask ? m_dead : cone.dead_list;
     const size_t n_live = live_k.size(), n_dead = dead_list.size();
     void* ws = nullptr;
-    rc = workspace_get(call.device, (n_live + n_dead) * sizeof(int32_t) + 256, &ws);
+    const size_t live_part = (n_live * sizeof(int32_t) + 15) & ~(size_t)15;   // (16-byte aligned lists)
+    rc = call_workspace(call, live_part + n_dead * sizeof(int32_t) + 256, &ws);
     if (rc) return rc;
     int32_t* d_live = (int32_t*)ws;
-    int32_t* d_dead = d_live + n_live;
+    int32_t* d_dead = (int32_t*)((char*)ws + live_part);
     // (the cached lists live as long as the circuit; a per-call list is waited for below)
-    if (n_live)
-        VQA_HIP(hipMemcpyAsync(d_live, live_k.data(), n_live * sizeof(int32_t), hipMemcpyHostToDevice, call.stream));
-    if (n_dead)
-        VQA_HIP(hipMemcpyAsync(d_dead, dead_list.data(), n_dead * sizeof(int32_t), hipMemcpyHostToDevice, call.stream));
+    if (n_live && (rc = call_upload(call, d_live, live_k.data(), n_live * sizeof(int32_t)))) return rc;
+    if (n_dead && (rc = call_upload(call, d_dead, dead_list.data(), n_dead * sizeof(int32_t)))) return rc;
     a.live = d_live;
     a.n_live = (int)n_live;
     a.need_psi = live_k[0] >= 0;

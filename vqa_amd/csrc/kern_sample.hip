@@ -27,11 +27,14 @@ struct Philox {
     int have;         // unused 32-bit words left in out
 
     __device__ void init(uint64_t seed, uint64_t stream, uint64_t row) {
+        // counter = (row low, row high ^ stream high, draw number, stream low): a call has fewer than
+        // 2^32 rows, so the row's high word is free to carry the stream's, and two calls with
+        // different stream ids never share a counter
         key0 = (uint32_t)seed;
         key1 = (uint32_t)(seed >> 32);
         c0 = (uint32_t)row;
-        c1 = (uint32_t)(row >> 32);
-        c3 = (uint32_t)stream ^ (uint32_t)(stream >> 32) * 0x9E3779B9u;
+        c1 = (uint32_t)(row >> 32) ^ (uint32_t)(stream >> 32);
+        c3 = (uint32_t)stream;
         draws = 0;
         have = 0;
     }
@@ -50,14 +53,14 @@ struct Philox {
         ++draws;
         have = 4;
     }
-    // uniform in (0, 1): 53 random bits, never 0
+    // uniform in (0, 1): (m + 1/2) / 2^52 with 52 random bits m, exact in double, never 0 or 1
     __device__ double uniform() {
         if (have == 0) block();
         const bool first = have == 4;
         const uint32_t a = first ? out[0] : out[2], b = first ? out[1] : out[3];
         have -= 2;
-        const uint64_t m = ((uint64_t)(a >> 5) << 26) | (uint64_t)(b >> 6);
-        return ((double)m + 0.5) * (1.0 / 9007199254740992.0);
+        const uint64_t m = ((uint64_t)(a >> 6) << 26) | (uint64_t)(b >> 6);
+        return ((double)m + 0.5) * (1.0 / 4503599627370496.0);
     }
 };
 

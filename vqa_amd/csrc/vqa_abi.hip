@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <memory>
 
 #include "vqa_core.h"
 
@@ -24,13 +25,24 @@ void set_error(const char* fmt, ...) {
 }
 
 // ---- per-device state ------------------------------------------------------
+// One stream and one growable workspace per device.  The workspace is shared by every circuit and
+// every caller's stream, so its users are ordered: a call locks the device for the time it queues
+// its work (DeviceGuard; two host threads cannot interleave their launches on one device), and a
+// call that takes the workspace first makes its stream wait for the event the previous user
+// recorded behind its last kernel.
 struct DeviceState {
     hipStream_t stream = nullptr;
     void* ws = nullptr;
     size_t ws_bytes = 0;
+    std::recursive_mutex call_mu;     // held while a call queues its work
+    hipEvent_t ws_event = nullptr;    // recorded behind the last user of the workspace
+    hipStream_t ws_stream = nullptr;  // that user's stream
+    bool ws_recorded = false;
+    bool ws_touched = false;          // the call in progress has taken the workspace
+    hipStream_t touch_stream = nullptr;
 };
 static std::mutex g_dev_mu;
-static std::map<int, DeviceState> g_dev;
+static std::map<int, std::unique_ptr<DeviceState>> g_dev;
 
 static int device_state(int device, DeviceState** out) {
     std::lock_guard<std::mutex> lk(g_dev_mu);
@@ -41,33 +53,105 @@ static int device_state(int device, DeviceState** out) {
         if (device < 0 || device >= count)
             VQA_FAIL(VQA_ENODEVICE, "device %d out of range (%d visible)", device, count);
         VQA_HIP(hipSetDevice(device));
-        DeviceState ds;
-        VQA_HIP(hipStreamCreateWithFlags(&ds.stream, hipStreamNonBlocking));
-        it = g_dev.emplace(device, ds).first;
+        std::unique_ptr<DeviceState> ds(new DeviceState());
+        VQA_HIP(hipStreamCreateWithFlags(&ds->stream, hipStreamNonBlocking));
+        VQA_HIP(hipEventCreateWithFlags(&ds->ws_event, hipEventDisableTiming));
+        it = g_dev.emplace(device, std::move(ds)).first;
     }
-    *out = &it->second;
+    *out = it->second.get();
     return VQA_OK;
 }
 
-int workspace_get(int device, size_t bytes, void** out) {
+// Locks a device for one call; on the way out, when the call took the workspace, records the event
+// the next user on another stream waits for.
+struct DeviceGuard {
+    DeviceState* ds = nullptr;
+    int lock(int device) {
+        DeviceState* d;
+        int rc = device_state(device, &d);
+        if (rc) return rc;
+        d->call_mu.lock();
+        ds = d;
+        return VQA_OK;
+    }
+    ~DeviceGuard() {
+        if (!ds) return;
+        if (ds->ws_touched) {
+            ds->ws_touched = false;
+            if (hipEventRecord(ds->ws_event, ds->touch_stream) == hipSuccess) {
+                ds->ws_recorded = true;
+                ds->ws_stream = ds->touch_stream;
+            }
+        }
+        ds->call_mu.unlock();
+    }
+};
+
+static int workspace_get(int device, hipStream_t stream, size_t bytes, void** out) {
     DeviceState* ds;
     int rc = device_state(device, &ds);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lk(g_dev_mu);
+    std::lock_guard<std::recursive_mutex> lk(ds->call_mu);
+    VQA_HIP(hipSetDevice(device));
     if (ds->ws_bytes < bytes) {
-        VQA_HIP(hipSetDevice(device));
         if (ds->ws) {
             VQA_HIP(hipDeviceSynchronize());
             VQA_HIP(hipFree(ds->ws));
             ds->ws = nullptr;
             ds->ws_bytes = 0;
+            ds->ws_recorded = false;
         }
         const size_t want = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
         hipError_t e = hipMalloc(&ds->ws, want);
         if (e != hipSuccess) VQA_FAIL(VQA_ENOMEM, "hipMalloc of %zu workspace bytes failed: %s", want, hipGetErrorString(e));
         ds->ws_bytes = want;
     }
+    if (ds->ws_recorded && ds->ws_stream != stream) VQA_HIP(hipStreamWaitEvent(stream, ds->ws_event, 0));
+    ds->ws_touched = true;
+    ds->touch_stream = stream;
     *out = ds->ws;
+    return VQA_OK;
+}
+
+int call_workspace(const EvalCall& call, size_t bytes, void** out) {
+    if (!call.fixed) return workspace_get(call.device, call.stream, bytes, out);
+    FixedScratch& f = *call.fixed;
+    const size_t at = (f.used + 255) & ~(size_t)255;
+    if (at > f.bytes || bytes > f.bytes - at)
+        VQA_FAIL(VQA_EUNSUPPORTED, "this call needs %zu bytes of working memory, the fixed region has %zu left", bytes,
+                 at > f.bytes ? (size_t)0 : f.bytes - at);
+    *out = f.base + at;
+    f.used = at + bytes;
+    return VQA_OK;
+}
+
+size_t call_workspace_room(const EvalCall& call) {
+    if (!call.fixed) return SIZE_MAX;
+    const size_t at = (call.fixed->used + 255) & ~(size_t)255;
+    return at > call.fixed->bytes ? 0 : call.fixed->bytes - at;
+}
+
+// copy kernel of call_upload: the bytes travel as a kernel argument
+struct UploadChunk {
+    uint4 v[192];   // 3 KiB of the 4 KiB a kernel's arguments may take
+};
+__global__ void k_upload(UploadChunk c, uint4* dst, int n16) {
+    if ((int)threadIdx.x < n16) dst[threadIdx.x] = c.v[threadIdx.x];
+}
+
+int call_upload(const EvalCall& call, void* d_dst, const void* src, size_t bytes) {
+    if (!call.fixed) {
+        if (bytes) VQA_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, call.stream));
+        return VQA_OK;
+    }
+    for (size_t off = 0; off < bytes; off += sizeof(UploadChunk)) {
+        UploadChunk c;
+        const size_t nb = std::min(sizeof(UploadChunk), bytes - off);
+        memset(&c, 0, sizeof(c));
+        memcpy(&c, (const char*)src + off, nb);
+        hipLaunchKernelGGL(k_upload, dim3(1), dim3(192), 0, call.stream, c, (uint4*)((char*)d_dst + off), (int)((nb + 15) / 16));
+    }
+    VQA_HIP(hipGetLastError());
     return VQA_OK;
 }
 
@@ -452,8 +536,8 @@ static int eval_dev_common(vqa_circuit* c, int device, void* stream, const doubl
     call.device = device;
     rc = pack_obs(c, obs, n_obs, &call.obs);
     if (rc) return rc;
-    DeviceState* ds;
-    rc = device_state(device, &ds);
+    DeviceGuard guard;
+    rc = guard.lock(device);
     if (rc) return rc;
     DeviceCtx* ctx;
     rc = circuit_device_ctx(c, device, &ctx);
@@ -647,9 +731,10 @@ int vqa_statevector(vqa_circuit* c, int device, const double* theta, const doubl
     if (c->n_theta > 0 && !theta) VQA_FAIL(VQA_EINVAL, "theta is NULL");
     if (c->n_input > 0 && !input_row) VQA_FAIL(VQA_EINVAL, "input_row is NULL");
     if (shift_param < -1 || shift_param >= c->n_theta) VQA_FAIL(VQA_EINVAL, "shift_param out of range");
-    DeviceState* ds;
-    int rc = device_state(device, &ds);
+    DeviceGuard guard;   // (the streaming engine's workspace: ordered against its other users)
+    int rc = guard.lock(device);
     if (rc) return rc;
+    DeviceState* ds = guard.ds;
     DeviceCtx* ctx;
     rc = circuit_device_ctx(c, device, &ctx);
     if (rc) return rc;

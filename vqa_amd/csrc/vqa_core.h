@@ -173,6 +173,14 @@ struct EvalCall {  // one batched evaluation, all pointers on the device
     ConeInfo* cone;  // what cannot matter for this call's observables (null: the state itself is asked for)
     double* d_out_expect;
     double* d_out_marginal;
+    struct FixedScratch* fixed = nullptr;  // non-null: the call must not allocate; its working memory is this region
+};
+
+// A fixed region of device memory that serves as a call's working memory (the allocation-free
+// entry point): handed out front to back, 256-byte aligned.
+struct FixedScratch {
+    char* base;
+    size_t bytes, used;
 };
 
 // engines: each returns VQA_OK or an error code with set_error() called
@@ -195,7 +203,15 @@ int fill_dead_rows(hipStream_t stream, double* d_out, int64_t n_samples, int K, 
 int sample_counts_launch(hipStream_t stream, const double* d_probs, int M, const int64_t* d_shots, int64_t E,
                          uint64_t seed, uint64_t stream_id, int64_t* d_counts);
 
-// per-device workspace owned by the library (grown on demand, never shrunk)
-int workspace_get(int device, size_t bytes, void** out);
+// Working memory of a call: the per-device workspace owned by the library (grown on demand, never
+// shrunk; users on different streams are ordered by an event) or, for a call with a fixed region,
+// the next `bytes` of that region (VQA_EUNSUPPORTED when it does not hold them).
+int call_workspace(const EvalCall& call, size_t bytes, void** out);
+// bytes a call may still ask for: SIZE_MAX for the growable workspace
+size_t call_workspace_room(const EvalCall& call);
+// host -> device copy of a small table on the call's stream: hipMemcpyAsync, or, for a call that must
+// not allocate (pageable copies stage through buffers the runtime may allocate), chunks passed
+// as kernel arguments to a copy kernel.  d_dst 16-byte aligned, with room for bytes rounded up to 16.
+int call_upload(const EvalCall& call, void* d_dst, const void* src, size_t bytes);
 
 }  // namespace vqa

@@ -138,6 +138,16 @@ class LearningCircuit(GateList):
         ``[B, n_input]`` angle matrix resident on the GPU."""
         return self.to_device(self.input_angles(x_list), np.float64)
 
+    def _on_stream(self, stream):
+        """Context in which torch's current stream is `stream` (a torch.cuda.Stream, or a raw
+        hipStream_t as an int): the temporaries and outputs of a call are then allocated on the
+        stream the library's kernels run on, so the caching allocator cannot hand their memory
+        out again while those kernels are still running."""
+        torch = _torch()
+        if not isinstance(stream, torch.cuda.Stream):
+            stream = torch.cuda.ExternalStream(int(stream), device=self.device)
+        return torch.cuda.stream(stream)
+
     def _obs_array(self, obs_list):
         arr = (C.c_void_p * max(len(obs_list), 1))()
         for i, o in enumerate(obs_list):
@@ -224,6 +234,9 @@ class LearningCircuit(GateList):
         """Evaluate an explicit instance list.  ``inputs``: ``[B, n_input]``
         angles (numpy: host-pointer path; torch cuda tensor: device path).
         Returns ``(expect[E, n_obs], marginal[E, 2^m] or None)``."""
+        if stream is not None:
+            with self._on_stream(stream):
+                return self.eval_batch(theta, inputs, sample_idx, shift_param, shift_val, obs_list, n_marg_bits, device_out)
         if sample_idx is not None:
             n_inst = len(sample_idx)
         elif shift_param is not None:
@@ -233,7 +246,7 @@ class LearningCircuit(GateList):
         plan = self._basis_plan(obs_list, n_inst)
         if plan is not None:
             return self._run_split(plan, "eval_batch", (theta, inputs, sample_idx, shift_param, shift_val),
-                                   dict(device_out=device_out, stream=stream), n_marg_bits)
+                                   dict(device_out=device_out), n_marg_bits)
         torch = _torch()
         L = _lib.lib()
         n_obs, M = len(obs_list), 1 << n_marg_bits
@@ -266,7 +279,7 @@ class LearningCircuit(GateList):
         sv = None if shift_val is None else self.to_device(shift_val, np.float64)
         oe = torch.empty((E, n_obs), dtype=torch.float64, device=dev)
         om = torch.empty((E, M), dtype=torch.float64, device=dev) if n_marg_bits > 0 else None
-        st = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
+        st = torch.cuda.current_stream(self.device).cuda_stream
         p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
         _lib.check(L.vqa_eval_batch_dev(self.handle(), self.device, C.c_void_p(st), p(th), p(ia), B,
                                         p(si), p(sp), p(sv), E, oarr, n_obs, n_marg_bits,
@@ -291,11 +304,15 @@ class LearningCircuit(GateList):
         ``params``: indices of the parameters whose shifted rows are wanted (the
         others are zero or computed anyway); for sharding one circuit's shifts
         over several GPUs."""
+        if stream is not None:
+            with self._on_stream(stream):
+                return self.psr_full(theta, inputs, sel, n_sel, shift, obs_list, n_marg_bits, None, out_expect,
+                                     out_marginal, params)
         n_rows = n_sel if n_sel is not None else len(sel) if sel is not None else (1 if inputs is None else max(int(inputs.shape[0]), 1))
         plan = self._basis_plan(obs_list, n_rows * (2 * self.n_theta + 1))
         if plan is not None:
             return self._run_split(plan, "psr_full", (theta, inputs),
-                                   dict(sel=sel, n_sel=n_sel, shift=shift, stream=stream, out_expect=out_expect,
+                                   dict(sel=sel, n_sel=n_sel, shift=shift, out_expect=out_expect,
                                         out_marginal=out_marginal, params=params), n_marg_bits)
         torch = _torch()
         L = _lib.lib()
@@ -316,7 +333,7 @@ class LearningCircuit(GateList):
             om = out_marginal
             if om is None and n_marg_bits > 0:
                 om = torch.zeros((n_sel, K, M), dtype=torch.float64, device=dev)
-            st = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
+            st = torch.cuda.current_stream(self.device).cuda_stream
             p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
             _lib.check(L.vqa_psr_params_dev(self.handle(), self.device, C.c_void_p(st), p(th), p(ia), B, p(se), n_sel,
                                             float(shift), _lib.nptr(mask), oarr, n_obs, n_marg_bits,
@@ -342,7 +359,7 @@ class LearningCircuit(GateList):
         om = out_marginal
         if om is None and n_marg_bits > 0:
             om = torch.empty((n_sel, K, M), dtype=torch.float64, device=dev)
-        st = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
+        st = torch.cuda.current_stream(self.device).cuda_stream
         p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
         _lib.check(L.vqa_psr_full_dev(self.handle(), self.device, C.c_void_p(st), p(th), p(ia), B,
                                       p(se), n_sel, float(shift), oarr, n_obs, n_marg_bits,

@@ -110,8 +110,27 @@ class PauliSumVQE:
             return self.offset + Et @ self.coefs
         nt = self._deal_shots(n)
         self.shots_counter[0] += int(nt.sum())
-        est = Et + np.random.randn(*Et.shape) * np.sqrt(np.clip(1.0 - Et ** 2, 0.0, None) / nt)
+        est = Et + self._noise(Et.shape) * np.sqrt(np.clip(1.0 - Et ** 2, 0.0, None) / nt)
         return self.offset + est @ self.coefs
+
+    def _noise(self, shape):
+        """Standard normal deviates from NumPy's global generator.  With the parameters sharded over
+        a process group every rank must see the SAME estimates (or the ranks' parameters drift
+        apart): rank 0 draws and broadcasts; the other ranks draw as well and discard, so that
+        their generators advance alike."""
+        z = np.random.randn(*shape)
+        group = getattr(self, "group", None)
+        if group is None:
+            return z
+        import torch
+        import torch.distributed as dist
+
+        if dist.get_world_size(group) == 1:
+            return z
+        dev = getattr(self._inputs, "device", "cpu") if dist.get_backend(group) == "nccl" else "cpu"
+        t = torch.from_numpy(z).to(dev)
+        dist.broadcast(t, src=dist.get_global_rank(group, 0), group=group)
+        return t.cpu().numpy()
 
     # ---- the optimizer-facing methods ----------------------------------------------------
     def exact_energy(self, params):
