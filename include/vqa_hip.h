@@ -29,6 +29,7 @@
 #ifndef VQA_HIP_H
 #define VQA_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -199,6 +200,30 @@ int vqa_psr_full_dev(vqa_circuit* c, int device, void* stream,
                      const int32_t* d_sel, int n_sel, double shift,
                      const vqa_obs* const* obs, int n_obs, int n_marg_bits,
                      double* d_out_expect, double* d_out_marginal);
+
+/*
+ * vqa_psr_full_dev that allocates nothing.  No counterpart in the reference: it is for callers
+ * that cannot allocate device memory when they call -- code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc.  Same arguments, same outputs.  Everything the
+ * sweep needs besides the caller's inputs and outputs (the compiled program, the work counter,
+ * the run lists, the state images and run records of the sweep's workgroups) lives in a static
+ * device array of VQA_NOALLOC_SCRATCH_BYTES (32 MiB) that every GPU the library runs on holds until the
+ * process ends; small host tables reach it as kernel arguments of a copy kernel, not through
+ * hipMemcpy.  The call makes no hipMalloc / hipFree and uses no library workspace.
+ *
+ * Limits: circuits served by the register engine (4 to 14 qubits, Z-basis observables, at most
+ * 6 marginal bits); the array must hold the program plus one workgroup's area, else
+ * VQA_EUNSUPPORTED with the sizes in the message (14 qubits: up to about 120 diagonal stages).
+ * The sweep launches as many workgroups as the array has areas for, so large circuits run on a
+ * part of the GPU: this entry point trades speed for the guarantee.  All calls on one GPU share
+ * that GPU's array: calls that overlap in time on one GPU race; order them on one stream.
+ */
+#define VQA_NOALLOC_SCRATCH_BYTES ((size_t)32 << 20)
+int vqa_psr_full_noalloc_dev(vqa_circuit* c, int device, void* stream,
+                             const double* d_theta, const double* d_input_angles, int B,
+                             const int32_t* d_sel, int n_sel, double shift,
+                             const vqa_obs* const* obs, int n_obs, int n_marg_bits,
+                             double* d_out_expect, double* d_out_marginal);
 
 /*
  * vqa_psr_full_dev for a SUBSET of the parameters: param_mask is a HOST array of P bytes

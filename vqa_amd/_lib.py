@@ -21,6 +21,7 @@ EXPORTS = (
     "vqa_observable_create", "vqa_observable_destroy",
     "vqa_eval_batch", "vqa_eval_batch_dev", "vqa_psr_full", "vqa_psr_full_dev",
     "vqa_statevector", "vqa_sample_counts", "vqa_sample_counts_dev", "vqa_dead_parameters", "vqa_psr_params_dev",
+    "vqa_psr_full_noalloc_dev",
 )
 
 
@@ -64,6 +65,7 @@ def lib():
                                vp, C.c_int, C.c_int, dp, dp]
     L.vqa_psr_full_dev.argtypes = [vp, C.c_int, vp, dp, dp, C.c_int, ip, C.c_int, C.c_double,
                                    vp, C.c_int, C.c_int, dp, dp]
+    L.vqa_psr_full_noalloc_dev.argtypes = L.vqa_psr_full_dev.argtypes
     L.vqa_statevector.argtypes = [vp, C.c_int, dp, dp, C.c_int, C.c_double, dp]
     L.vqa_psr_params_dev.argtypes = [vp, C.c_int, vp, dp, dp, C.c_int, ip, C.c_int, C.c_double, vp,
                                      vp, C.c_int, C.c_int, dp, dp]

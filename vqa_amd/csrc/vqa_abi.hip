@@ -277,23 +277,28 @@ static int resolve_engine(const vqa_circuit* c) { return c->engine; }
 
 // Engine 2 runs the circuit WITHOUT the gates outside the call's light cone: the program of
 // that pruned gate list (compiled on first use; the circuit's own program when it has nothing to
-// prune or the pruned list does not compile for sweeps) and its copy on the call's device.
+// prune or the pruned list does not compile for sweeps).  Caller holds the circuit's mutex.
+static void cone_reg_program_host(const EvalCall& call) {
+    ConeInfo& cone = *call.cone;
+    if (cone.reg_tried) return;
+    cone.reg_tried = true;
+    if (cone.n_gate_dead > 0) {
+        std::vector<vqa_op> live;
+        for (int g = 0; g < call.c->n_ops; ++g)
+            if (!cone.gate_dead[g]) live.push_back(call.c->ops[g]);
+        auto rp = std::make_shared<RegProgram>();
+        std::string why;
+        if (reg_compile(call.c->n_qubits, call.c->n_theta, live, rp.get(), &why) &&
+            reg_engine_can_sweep(*rp) == reg_engine_can_sweep(*call.c->reg))
+            cone.reg = rp;
+    }
+}
+
+// ... and its copy on the call's device.
 static int cone_reg_program(const EvalCall& call, const RegProgram** prog, void** d_prog) {
     ConeInfo& cone = *call.cone;
     std::lock_guard<std::mutex> lk(call.c->mu);
-    if (!cone.reg_tried) {
-        cone.reg_tried = true;
-        if (cone.n_gate_dead > 0) {
-            std::vector<vqa_op> live;
-            for (int g = 0; g < call.c->n_ops; ++g)
-                if (!cone.gate_dead[g]) live.push_back(call.c->ops[g]);
-            auto rp = std::make_shared<RegProgram>();
-            std::string why;
-            if (reg_compile(call.c->n_qubits, call.c->n_theta, live, rp.get(), &why) &&
-                reg_engine_can_sweep(*rp) == reg_engine_can_sweep(*call.c->reg))
-                cone.reg = rp;
-        }
-    }
+    cone_reg_program_host(call);
     if (!cone.reg) return VQA_OK;
     auto it = cone.reg_dev.find(call.device);
     if (it == cone.reg_dev.end()) {
@@ -673,6 +678,87 @@ int vqa_psr_full(vqa_circuit* c, int device, const double* theta, const double* 
     if (n_marg_bits > 0) VQA_HIP(hipMemcpyAsync(out_marginal, dom.p, E * M * 8, hipMemcpyDeviceToHost, s));
     VQA_HIP(hipStreamSynchronize(s));
     return VQA_OK;
+}
+
+// ---- the sweep entry point that allocates nothing ------------------------------------------------
+// Working memory of vqa_psr_full_noalloc_dev: the compiled program, the work counter, the run
+// lists, and per workgroup the state images and run records of a sweep, all inside this array.
+// Every GPU the library runs on holds its own copy until the process ends.  (Size:
+// VQA_NOALLOC_SCRATCH_BYTES of include/vqa_hip.h.)
+static __device__ __align__(256) unsigned char scratch[VQA_NOALLOC_SCRATCH_BYTES];
+constexpr int kMaxScratchDevices = 64;
+static std::mutex g_scratch_mu;
+static void* g_scratch_ptr[kMaxScratchDevices];   // device address of `scratch` on each GPU (null: not asked yet)
+
+// The array's name is a host-side stand-in, not a device address: the address on `device` comes
+// from hipGetSymbolAddress, once per device, with that device current.
+static int scratch_address(int device, void** out) {
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[device]) {
+        void* ptr = nullptr;
+        VQA_HIP(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
+        if (!ptr) VQA_FAIL(VQA_EHIP, "hipGetSymbolAddress returned a null address for the scratch array");
+        g_scratch_ptr[device] = ptr;
+    }
+    *out = g_scratch_ptr[device];
+    return VQA_OK;
+}
+
+int vqa_psr_full_noalloc_dev(vqa_circuit* c, int device, void* stream, const double* d_theta,
+                             const double* d_input_angles, int B, const int32_t* d_sel, int n_sel,
+                             double shift, const vqa_obs* const* obs, int n_obs, int n_marg_bits,
+                             double* d_out_expect, double* d_out_marginal) {
+    if (!c) VQA_FAIL(VQA_EINVAL, "circuit handle is NULL");
+    if (n_sel < 0) VQA_FAIL(VQA_EINVAL, "n_sel must be >= 0");
+    if (!d_sel && c->n_input > 0 && n_sel > B)
+        VQA_FAIL(VQA_EINVAL, "sel is NULL but n_sel (%d) > B (%d)", n_sel, B);
+    int rc = check_common(c, device, d_theta, d_input_angles, B, n_obs, n_marg_bits, d_out_expect, d_out_marginal);
+    if (rc) return rc;
+    if (c->engine != 2 || !c->reg)
+        VQA_FAIL(VQA_EUNSUPPORTED, "the allocation-free sweep serves circuits of the register engine (4 to 14 qubits); "
+                                   "this circuit runs on engine %d", c->engine);
+    int count = 0;
+    VQA_HIP(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count || device >= kMaxScratchDevices)
+        VQA_FAIL(VQA_ENODEVICE, "device %d out of range (%d visible)", device, count);
+    VQA_HIP(hipSetDevice(device));
+    void* base = nullptr;
+    if ((rc = scratch_address(device, &base))) return rc;
+    if (n_sel == 0) return VQA_OK;
+    FixedScratch fx = { (char*)base, VQA_NOALLOC_SCRATCH_BYTES, 0 };
+    EvalCall call;
+    call.c = c;
+    call.device = device;
+    rc = pack_obs(c, obs, n_obs, &call.obs);
+    if (rc) return rc;
+    call.stream = (hipStream_t)stream;
+    call.d_ops = nullptr;   // (the register engine reads its compiled program, not the op table)
+    call.d_theta = d_theta;
+    call.d_input = d_input_angles;
+    call.spec = EvalSpec{ nullptr, nullptr, nullptr, d_sel, 1, c->n_theta, shift, c->n_input > 0 ? B : 0, c->n_theta };
+    call.E = (int64_t)n_sel * (2 * (int64_t)c->n_theta + 1);
+    call.n_marg_bits = n_marg_bits;
+    call.n_sweep = n_sel;
+    call.cone = cone_of(c, call.obs, n_marg_bits);
+    call.param_mask = nullptr;
+    call.d_out_expect = d_out_expect;
+    call.d_out_marginal = d_out_marginal;
+    call.fixed = &fx;
+    // the program of the gate list without the gates outside the light cone (host copy; compiled
+    // when the cone is first seen), brought to the front of the scratch array on every call: the
+    // array keeps whatever the last call left there, possibly another circuit's program
+    const RegProgram* prog = c->reg.get();
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        cone_reg_program_host(call);
+        if (call.cone->reg) prog = call.cone->reg.get();
+    }
+    void* d_prog = nullptr;
+    if ((rc = call_workspace(call, prog->blob.size(), &d_prog))) return rc;
+    if ((rc = call_upload(call, d_prog, prog->blob.data(), prog->blob.size()))) return rc;
+    if (reg_engine_can_sweep(*c->reg) && reg_engine_can_sweep(*prog)) return reg_engine_sweep(call, d_prog, *prog, n_sel);
+    if (reg_engine_can_group(*prog)) return reg_engine_group(call, d_prog, *prog, n_sel);
+    return reg_engine_run(call, d_prog, *prog);
 }
 
 int vqa_dead_parameters(vqa_circuit* c, const vqa_obs* const* obs, int n_obs, int n_marg_bits, uint8_t* out_dead) {
