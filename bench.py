@@ -11,14 +11,18 @@ P+1 gradient sums over RCCL.  Every one of the B * (2P+1) expectation values is
 computed and written each step; the sweep kernel shares the unshifted prefix of
 a sample's circuit between its shifted evaluations ("prefix_reuse").
 
-The roofline object prices the sweep kernel against the FP64 vector unit, the
+The roofline object places the sweep kernel on the FP64 vector unit, the
 resource rocprof shows it bound by (state vectors of 12 qubits live in
-registers and LDS, HBM only sees inputs and results).  "achieved" counts the
-ALGORITHMIC work of the submitted, unfused gate list, so it can exceed the
-peak: the engine fuses gates, drops redundant phases and reuses prefixes.
+registers and LDS).  "achieved" / "frac" are the FP64 work the kernel EXECUTES
+(PMC instruction counts of the committed profile of this same command, per
+evaluation) at the launch time measured live; the ALGORITHMIC work of the
+submitted, unfused gate list is reported beside it ("alg_*"): it exceeds the
+peak because the engine fuses gates, drops redundant phases, reuses each
+sample's unshifted prefix and leaves out gates outside the light cone.
 
 Usage: python bench.py --gpus N --steps K --warmup W
-(N > 1: launched by torch.distributed.run, one rank per GPU.)
+(N > 1: either launched by torch.distributed.run, one rank per GPU, or started
+plainly: the parent then spawns its N ranks itself before it touches the GPU.)
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -79,6 +83,10 @@ def main():
     ap.add_argument("--share-gpu", action="store_true",
                     help="every rank on cuda:0 (rehearsal of the N > 1 path on a one-GPU box; not a valid number)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started plainly with --gpus N: this process becomes the launcher of N fresh rank processes
+        # (it has made no GPU call and imports nothing that does)
+        sys.exit(spawn_ranks(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -228,6 +236,9 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(circ, theta, ia, P, args.cpu_seconds)
         if not args.no_other_configs and world == 1 and args.workload == "hea12_d10_b65536" and not args.batch:
+            # the same step with the light-cone pruning switched off (every gate of every shifted circuit
+            # runs, nothing copied): what the sweep kernel does without that piece of circuit analysis
+            res["without_light_cone_pruning"] = unpruned_step(local_rank, n, d, d_theta, d_in, d_y, w, z0, B, d_out)
             d_out = d_in = None   # (the 3.3 GB of headline outputs: the 20-qubit sweep wants the memory)
             torch.cuda.empty_cache()
             res["other_configs"] = other_configs(local_rank)
@@ -272,42 +283,93 @@ def hbm_traffic_per_launch(evals):
 
 
 def roofline(bytes_alg, flops_alg, evals, kern_ms, measured):
+    """Position of the sweep kernel on the FP64 vector roofline.  achieved / frac: the FP64 flops the
+    kernel executes (SQ_INSTS_VALU_{FMA,MUL,ADD}_F64 of the committed profile, per evaluation) at the
+    launch duration measured now.  alg_*: the unfused gate list's work at the same duration."""
     per_s = evals / (kern_ms * 1e-3)
-    tflops = flops_alg * per_s / 1e12
-    gbs = bytes_alg * per_s / 1e9
+    alg_tflops = flops_alg * per_s / 1e12
+    alg_gbs = bytes_alg * per_s / 1e9
+    ex = profiled("fp64_flops_per_eval")
+    ex_tflops = None if ex is None else ex * per_s / 1e12
     r = {
         "kernel": "k_reg_psr",
-        # the compute roofline of the dtype: on gfx950 the FP64 MFMA peak equals the FP64 vector
-        # peak (78.6 TFLOP/s); the kernel issues vector FMAs, not MFMA (see bound_detail)
-        "bound": "mfma",
-        "bound_detail": "fp64 compute: vector-ALU FMAs (rocprof: VALU issue-bound), priced at the 78.6 TFLOP/s "
-                        "FP64 peak that MFMA and VALU share on gfx950; state vectors live in registers/LDS",
-        "achieved": tflops,
+        # FP64 vector ALU: the kernel issues v_fma_f64 / v_mul_f64, no MFMA (on gfx950 the FP64 MFMA
+        # peak equals the FP64 vector peak, 78.6 TFLOP/s, and a 2x2 gate is no GEMM)
+        "bound": "valu_fp64",
+        "achieved": ex_tflops,
         "peak": FP64_PEAK_TFLOPS,
         "unit": "TFLOP/s",
-        "frac": tflops / FP64_PEAK_TFLOPS,
+        "frac": None if ex_tflops is None else ex_tflops / FP64_PEAK_TFLOPS,
         "traffic": hbm_traffic_per_launch(evals),
         "kernel_ms_per_launch": kern_ms,
         "evals_per_launch": evals,
+        "executed_fp64_flops_per_eval": ex,
+        "fp64_issue_frac": None if ex is None else profiled("fp64_wave_instr_per_eval") * per_s * 4.0 / (1024 * 2.4e9),
+        "profile_source": profiled_str("source"),
+        # the submitted, unfused gate list priced the same way (ratios above 1: work the engine never does)
         "alg_flops_per_eval": flops_alg,
         "alg_bytes_per_eval": bytes_alg,
-        "note": "algorithmic work of the unfused gate list; > 1 is possible because the engine fuses gates and "
-                "reuses each sample's unshifted prefix; executed-instruction fractions are in profiles/",
-        # the same algorithmic state traffic priced against the two memory levels it could have lived in
-        "lds": {"achieved": gbs, "peak": LDS_PEAK_GBS, "unit": "GB/s", "frac": gbs / LDS_PEAK_GBS},
-        "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS},
+        "alg_achieved": alg_tflops,
+        "alg_frac": alg_tflops / FP64_PEAK_TFLOPS,
+        "alg_over_executed": None if ex is None else flops_alg / ex,
+        "alg_lds_frac": alg_gbs / LDS_PEAK_GBS,
+        "alg_hbm_frac": alg_gbs / HBM_PEAK_GBS,
+        "hbm_traffic_frac": None if hbm_traffic_per_launch(evals) is None
+        else hbm_traffic_per_launch(evals) / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
     }
-    ex = profiled("fp64_flops_per_eval")
-    if ex is not None:
-        # what the kernel executes (PMC instruction counts of the profiled run) at the rate measured now
-        r["executed"] = {"achieved": ex * per_s / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ex * per_s / 1e12 / FP64_PEAK_TFLOPS, "fp64_flops_per_eval": ex,
-                         "fp64_issue_frac": profiled("fp64_wave_instr_per_eval") * per_s * 4.0 / (1024 * 2.4e9)}
     if measured:
         r["measured_peaks"] = measured
-        if "fp64_fma_tflops" in measured:
-            r["frac_of_measured_peak"] = tflops / measured["fp64_fma_tflops"]
+        if "fp64_fma_tflops" in measured and ex_tflops is not None:
+            r["frac_of_measured_peak"] = ex_tflops / measured["fp64_fma_tflops"]
     return r
+
+
+def profiled_str(key):
+    try:
+        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+            return str(json.load(f)[key])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def unpruned_step(device, n, d, d_theta, d_in, d_y, w, z0, B, d_out):
+    """One timed step on a fresh circuit object created with VQA_NO_CONE set (the library reads the
+    switch when it first analyses a circuit for a set of measured qubits)."""
+    import torch
+
+    from vqa_amd import LearningCircuit, create_ibm_HEA_ansatz
+    from vqa_amd.distributed import sharded_mse_gradient
+
+    os.environ["VQA_NO_CONE"] = "1"
+    try:
+        c = create_ibm_HEA_ansatz(n, d, seed=0, circuit_cls=lambda nq: LearningCircuit(nq, device=device))
+        sharded_mse_gradient(c, d_theta, d_in[:512], d_y[:512], w, z0, n_global=512, out_expect=d_out[:512])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sharded_mse_gradient(c, d_theta, d_in, d_y, w, z0, n_global=B, out_expect=d_out)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        del os.environ["VQA_NO_CONE"]
+    return {"gradients_per_sec": B / dt, "ms_per_step": 1e3 * dt, "steps": 1}
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` started plainly: N child processes of this same command, one rank
+    per GPU, rendezvous on 127.0.0.1; rank 0's JSON line goes to the inherited stdout.  Returns the
+    largest exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    return max(p.wait() for p in procs)
 
 
 def other_configs(device):
@@ -319,7 +381,7 @@ def other_configs(device):
 
     out = {}
     for name, n, d, B, n_feat, reps in (("sin(x) regressor: 6 qubits, depth 5, batch 4096", 6, 5, 4096, 1, 5),
-                                        ("20-qubit QNN: depth 8 (HBM engine), 4 of the batch's 1024 samples", 20, 8, 4, 20, 1)):
+                                        ("20-qubit QNN: depth 8 (HBM engine), batch 1024", 20, 8, 1024, 20, 1)):
         rng = np.random.default_rng(1)
         c = create_ibm_HEA_ansatz(n, d, seed=0, circuit_cls=lambda nq: LearningCircuit(nq, device=device))
         x = c.upload_inputs(rng.uniform(0.0, np.pi, (B, n_feat)))

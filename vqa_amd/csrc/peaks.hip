@@ -44,10 +44,27 @@ __global__ __launch_bounds__(256) void k_lds(double* out, int iters) {
     if (acc.x == 12345.678) out[0] = acc.y;
 }
 
-__global__ __launch_bounds__(256) void k_copy(const double2* __restrict__ src, double2* __restrict__ dst, size_t n) {
-    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) dst[i] = src[i];
+// Copy of n 16-byte words: a workgroup takes a contiguous tile of 256 * U words and every lane
+// issues its U loads before its first store (U requests in flight per lane, each wave-instruction a
+// contiguous 1 KiB).  NT: non-temporal loads and stores (a stream that is read and written once).
+typedef float float4v __attribute__((ext_vector_type(4)));
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void k_copy(const float4v* __restrict__ src, float4v* __restrict__ dst, size_t n) {
+    const size_t base = (size_t)blockIdx.x * (256 * U) + threadIdx.x;
+    float4v v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const size_t i = base + (size_t)u * 256;
+        if (i < n) v[u] = NT ? __builtin_nontemporal_load(src + i) : src[i];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const size_t i = base + (size_t)u * 256;
+        if (i < n) {
+            if (NT) __builtin_nontemporal_store(v[u], dst + i);
+            else dst[i] = v[u];
+        }
+    }
 }
 
 template <class F>
@@ -104,23 +121,38 @@ int vqa_peak_lds(int device, double* gbs) {
     return 0;
 }
 
-// HBM copy bandwidth (bytes read + bytes written) in GB/s on a 2 x 1 GiB pair.
-int vqa_peak_hbm_copy(int device, double* gbs) {
+// HBM copy bandwidth (bytes read + bytes written) in GB/s on a 2 x 2 GiB pair (far beyond the
+// 256 MiB Infinity Cache): the best of a few shapes of the same copy; variant[] (may be null)
+// receives the rate of each: {U=4, U=8, U=4 non-temporal, U=8 non-temporal}.
+int vqa_peak_hbm_copy_variants(int device, double* gbs, double* variant) {
     if (hipSetDevice(device) != hipSuccess) return -1;
-    hipDeviceProp_t p;
-    if (hipGetDeviceProperties(&p, device) != hipSuccess) return -1;
-    const size_t bytes = (size_t)1 << 30, n = bytes / sizeof(double2);
-    double2 *a = nullptr, *b = nullptr;
+    const size_t bytes = (size_t)2 << 30, n = bytes / sizeof(float4v);
+    float4v *a = nullptr, *b = nullptr;
     if (hipMalloc(&a, bytes) != hipSuccess) return -1;
     if (hipMalloc(&b, bytes) != hipSuccess) { hipFree(a); return -1; }
     hipMemset(a, 1, bytes);
-    double ms = 0;
-    int rc = timed([&] { hipLaunchKernelGGL(k_copy, dim3(p.multiProcessorCount * 8), dim3(256), 0, 0, a, b, n); }, 5, &ms);
+    double best = 0.0;
+    int rc = 0;
+    for (int k = 0; k < 4 && !rc; ++k) {
+        const int U = (k & 1) ? 8 : 4;
+        const unsigned blocks = (unsigned)((n + 256 * (size_t)U - 1) / (256 * (size_t)U));
+        double ms = 0;
+        rc = timed([&] {
+            if (k == 0) hipLaunchKernelGGL((k_copy<4, false>), dim3(blocks), dim3(256), 0, 0, a, b, n);
+            else if (k == 1) hipLaunchKernelGGL((k_copy<8, false>), dim3(blocks), dim3(256), 0, 0, a, b, n);
+            else if (k == 2) hipLaunchKernelGGL((k_copy<4, true>), dim3(blocks), dim3(256), 0, 0, a, b, n);
+            else hipLaunchKernelGGL((k_copy<8, true>), dim3(blocks), dim3(256), 0, 0, a, b, n);
+        }, 5, &ms);
+        const double r = 2.0 * bytes / (ms * 1e-3) / 1e9;
+        if (variant) variant[k] = r;
+        if (r > best) best = r;
+    }
     hipFree(a);
     hipFree(b);
     if (rc) return rc;
-    *gbs = 2.0 * bytes / (ms * 1e-3) / 1e9;
+    *gbs = best;
     return 0;
 }
+int vqa_peak_hbm_copy(int device, double* gbs) { return vqa_peak_hbm_copy_variants(device, gbs, nullptr); }
 
 }  // extern "C"
