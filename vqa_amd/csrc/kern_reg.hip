@@ -179,7 +179,7 @@ __device__ __forceinline__ double elem_angle_c(const VQA_CAS ElemGate* g, const 
 // Fused 2x2 of U-entry u -> e^{i d} RZ(al) RY(be) RZ(ga) with c, s = (cos, sin)(be/2)
 // >= 0, A = e^{i al/2}, G = e^{i ga/2}.  The table entry m the rotation code reads:
 //   register bit:            (tan(be/4), s)   three shears, exact
-//   lane bit, !SCALED:       (c, s)           x <- c x +- s partner
+//   lane bit, !SCALED, and lane bits 4 / 5 (on_lane == 2):  (c, s)   x <- c x +- s partner
 //   lane bit, SCALED, c >= s: (s/c, 0)        x <- x +- (s/c) partner        (state / c)
 //   lane bit, SCALED, c <  s: (c/s, 1)        x <- +-(c/s) x + partner       (state / s, and a
 //       sign flip of the |1> half, which is a Z after the rotation: RZ(al) Z = i RZ(al - pi),
@@ -253,7 +253,7 @@ __device__ __forceinline__ void compute_uentry(const Prog& pp, int u, const doub
     if (pp.uent[u].d_before < 0) gp = cmul(gp, G);
     if (!pp.uent[u].on_lane) {
         m = make_double2(sn / (1.0 + c), sn);
-    } else if (!SCALED) {
+    } else if (!SCALED || pp.uent[u].on_lane == 2) {   // (2: rotated by the matrix unit, exact form)
         m = make_double2(c, sn);
     } else if (c >= sn) {
         m = make_double2(sn / c, 0.0);
@@ -515,6 +515,37 @@ __device__ __forceinline__ void apply_ulane(double2 (&amp)[kRegAmps], double m0,
 #undef VQA_LANE_UPD
 }
 
+// Rotations on lane bits 4 and 5 through the matrix unit.  v_mfma_f64_4x4x4_4b_f64 computes, for
+// every lane l = 16 i + 4 b + j,  D[l] = sum_k A[16 k + 4 b + i] * B[16 k + 4 b + j]  (layout found
+// by experiment, tools/micro/mfma_f64.hip): the contraction runs over lane bits 4 and 5 of B, and the
+// result comes back in the same lanes.  With B = one register of the state and A = the 4x4 real
+// matrix R5 (x) R4 of the two rotations, ONE instruction per register rotates both qubits, at the
+// price of two register-bit rotations (16 cycles; two lane rotations through DPP cost 27, through
+// the LDS crossbar more).  The FP64 matrix unit shares its arithmetic with the vector unit on
+// gfx950 (measured: no overlap between an MFMA stream and an FMA stream on one SIMD), so this is
+// fewer vector-unit cycles, not a second pipe.
+// (c4, s4), (c5, s5): cos, sin of half the rotation angles; an absent rotation is (1, 0).
+__device__ __forceinline__ void apply_ulane45(double2 (&amp)[kRegAmps], double c4, double s4, double c5, double s5, int lane) {
+    const unsigned i0 = lane & 1u, i1 = (lane >> 1) & 1u, k0 = (lane >> 4) & 1u, k1 = (lane >> 5) & 1u;
+    // R[out][in] = [[c, s], [-s, c]]
+    const double r4 = (i0 ^ k0) ? flip_if(s4, i0) : c4;
+    const double r5 = (i1 ^ k1) ? flip_if(s5, i1) : c5;
+    const double A = r4 * r5;
+    // the registers below were last written from inline assembly, which the compiler's hazard
+    // padding does not see (same on the way out)
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 4");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < kRegAmps; ++r) {
+        amp[r].x = __builtin_amdgcn_mfma_f64_4x4x4f64(A, amp[r].x, 0.0, 0, 0, 0);
+        amp[r].y = __builtin_amdgcn_mfma_f64_4x4x4f64(A, amp[r].y, 0.0, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 15");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // State images in global memory are [amplitude r][thread] and are moved with buffer
 // instructions: one resource for the workgroup's area, a uniform byte offset per
 // image and amplitude, one 32-bit per-thread offset.  All sixteen accesses of a state
@@ -732,8 +763,14 @@ __device__ __forceinline__ void run_phases(double2 (&amp)[kRegAmps], const Prog&
             if (run && form_b != 0) apply_ulane<LB, 2>(amp, cs.x, cs.y, cx.lane()); \
         }                                                                  \
         cs = csn;
-        VQA_LANE_SLOT(0) VQA_LANE_SLOT(1) VQA_LANE_SLOT(2) VQA_LANE_SLOT(3) VQA_LANE_SLOT(4) VQA_LANE_SLOT(5)
+        VQA_LANE_SLOT(0) VQA_LANE_SLOT(1) VQA_LANE_SLOT(2) VQA_LANE_SLOT(3)
 #undef VQA_LANE_SLOT
+        // lane bits 4 and 5: both rotations in one pass through the matrix unit (cs = entry of bit 4)
+        if (flags & (PH_ULANE0 * 0x30)) {
+            const double2 c5 = cx.mat[ent[9]];
+            const bool h4 = (flags & (PH_ULANE0 << 4)) != 0, h5 = (flags & (PH_ULANE0 << 5)) != 0;
+            apply_ulane45(amp, h4 ? cs.x : 1.0, h4 ? cs.y : 0.0, h5 ? c5.x : 1.0, h5 ? c5.y : 0.0, cx.lane());
+        }
         VQA_STAMP(12)
         if (flags & PH_DIAG) {
             const int did = d0.z;

@@ -255,7 +255,8 @@ bool reg_compile(int n, int n_theta, const std::vector<vqa_op>& gate_list, RegPr
     auto emit = [&](int kind, int a, int b) { P.ops.push_back(RegOp{ kind, a, b, 0 }); };
     auto emit_direct = [&](int q, int ue) {
         const int p = lay.pos_of[q];
-        P.uent[ue].on_lane = p >= R;
+        // 1: rotated through DPP partner fetches; 2: lane bits 4 / 5, rotated by the matrix unit
+        P.uent[ue].on_lane = p < R ? 0 : (p - R >= 4 ? 2 : 1);
         if (p < R) emit(ROP_UREG, p, ue);
         else emit(ROP_ULANE, p - R, ue);
     };
@@ -263,11 +264,25 @@ bool reg_compile(int n, int n_theta, const std::vector<vqa_op>& gate_list, RegPr
     // transpositions, no lane rotations); default: register bits and the cheap lane bits
     const char* sched_env = getenv("VQA_REG_SCHED");
     const int sched = sched_env ? atoi(sched_env) : 0;
-    auto cheap = [&](int p) { return p < R || (sched == 0 && (p == R + 0 || p == R + 1 || p == R + 3)); };
+    // Cost classes of a position (vector-unit cycles per rotation of a 16-amplitude thread, measured):
+    // register bit 216; lane bits 4 and 5 together through the matrix unit 522 for the pair; lane
+    // bits 0, 1, 3 through DPP 464 each; lane bit 2 (two DPP moves per word) more; wave bits: not at all.
+    // sched 0: register bits + the matrix-unit pair are "cheap"; DPP lanes only take what a
+    // transposition's slots cannot hold.  2: as before the matrix unit was used (DPP lanes cheap).
+    const bool mfma_pair = sched == 0 && L >= 6;
+    auto cheap = [&](int p) {
+        if (p < R) return true;
+        if (sched == 1) return false;
+        if (mfma_pair) return p == R + 4 || p == R + 5;
+        return p == R + 0 || p == R + 1 || p == R + 3;
+    };
+    auto dpp_lane = [&](int p) { return p == R + 0 || p == R + 1 || p == R + 3; };
     // slots a transposition may bring a qubit to: every cheap position but register bit R-1,
     // which stays where it is so that a transposition can run in two halves
-    const int n_swap_slots = sched == 1 ? 3 : 6;
-    const int cheap_slots[6] = { 0, 1, 2, R + 0, R + 1, R + 3 };
+    const int n_swap_slots = sched == 1 ? 3 : mfma_pair ? 5 : 6;
+    const int slots_dpp[6] = { 0, 1, 2, R + 0, R + 1, R + 3 };
+    const int slots_mfma[6] = { 0, 1, 2, R + 4, R + 5, -1 };
+    const int* cheap_slots = mfma_pair ? slots_mfma : slots_dpp;
 
     for (int u = 0; u < NU; ++u) {
         std::vector<std::pair<int, int>> byq;  // (position, qubit)
@@ -276,11 +291,24 @@ bool reg_compile(int n, int n_theta, const std::vector<vqa_op>& gate_list, RegPr
         if (W == 0) {
             for (auto& pq : byq) emit_direct(pq.second, uidx[u][pq.second]);
         } else {
-            std::vector<int> remaining;
+            std::vector<int> remaining, direct;
             for (auto& pq : byq) {
-                if (cheap(pq.first)) emit_direct(pq.second, uidx[u][pq.second]);
+                if (cheap(pq.first)) direct.push_back(pq.second);
                 else remaining.push_back(pq.second);
             }
+            // what the slots of the transpositions to come cannot hold goes through DPP now, where it
+            // sits on a lane bit that allows it (one DPP rotation is cheaper than another transposition)
+            if (mfma_pair) {
+                for (size_t i = 0; i < remaining.size() && remaining.size() % n_swap_slots != 0 && remaining.size() > (size_t)n_swap_slots;) {
+                    if (dpp_lane(lay.pos_of[remaining[i]])) {
+                        direct.push_back(remaining[i]);
+                        remaining.erase(remaining.begin() + i);
+                    } else ++i;
+                }
+            }
+            // in position order: one phase of the kernel's loop takes them all
+            std::sort(direct.begin(), direct.end(), [&](int a, int b) { return lay.pos_of[a] < lay.pos_of[b]; });
+            for (int q : direct) emit_direct(q, uidx[u][q]);
             while (!remaining.empty()) {
                 bool any_wave = false;
                 for (int q : remaining) any_wave |= lay.pos_of[q] >= R + L;
