@@ -273,6 +273,36 @@ int vqa_sample_counts_dev(int device, void* stream, const double* d_probs, int n
                           int64_t* d_counts);
 
 /*
+ * Estimator epilogue of the regressor's gradient oracles, on the device.  From the matrix of exact
+ * expectation values of a sweep, d_expect[b * (2P+1) + k] (out_expect of vqa_psr_full_dev with one
+ * observable), the labels d_y[B] and the scale parameter w it computes, per gradient component
+ * c = 0..P (P = the scale parameter), sums over the B samples of the per-sample terms the
+ * reference reduces in NumPy after its Python loop nest:
+ *   out_sums[c * 8 + 0]  the gradient term: (w M0 - y) w (M+ - M-); c = P: 2 (-y M0 + w M0^2)
+ *                         (vqa/QNN/myQNNs_base.py:1378, 1393)
+ *   out_sums[c * 8 + 1]  its square
+ * and with want_variances (MSE_iEval, 1421-1596) the estimator polynomials of 1205-1316:
+ *   [2], [3]  conditional-variance estimate, shifted and unshifted part (c = P: [2] only)
+ *   [4], [5]  the forms taken when a batch mean comes out negative (1242-1248, 1274-1286)
+ *   [6]       second moment of the gradient term (1313)            ([7] unused)
+ * M are estimates of the exact values from n = floor(shots[c] * weight[b]) shots (weight NULL: 1;
+ * the unshifted evaluation uses n_shots0):  mode 0 exact values (min_approx_shots = -10), 1 normal
+ * approximation E + z sqrt((1 - E^2) / n) (892-905), 2 binomial finite-shot means (715-738), 3 the
+ * caller's d_estimates[B, 2P+1].  Unbiased powers as 843-847.  Random numbers: Philox keyed by
+ * `seed`, one stream per (sample, column); not the reference's NumPy sequence.
+ * d_workspace: vqa_mse_stats_workspace(B, P) bytes of device memory, the caller's.  Optional
+ * outputs: d_out_m0[B] (estimates of the unshifted value), d_out_grad_data[(P+1) * B] (the
+ * per-sample gradient terms, 'grad_data_list' of MSE_iEval).  Deterministic (fixed summation
+ * order); queued on `stream`, not waited for.
+ */
+int64_t vqa_mse_stats_workspace(int64_t B, int P);
+int vqa_mse_stats_dev(int device, void* stream, const double* d_expect, const double* d_estimates,
+                      int64_t B, int P, const double* d_y, double w, const double* d_shots,
+                      const double* d_weight, double n_shots0, int mode, uint64_t seed,
+                      int want_variances, double n0, int second_order, double* d_workspace,
+                      double* d_out_sums, double* d_out_m0, double* d_out_grad_data);
+
+/*
  * Final state of ONE instance, interleaved (re, im) doubles, 2 * 2^n values,
  * host pointer.  For plumbing tests of the per-sample circuit.run(x) shim
  * (vqa/QNN/myQNNs_base.py:913); not a hot-path call.

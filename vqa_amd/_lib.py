@@ -21,7 +21,7 @@ EXPORTS = (
     "vqa_observable_create", "vqa_observable_destroy",
     "vqa_eval_batch", "vqa_eval_batch_dev", "vqa_psr_full", "vqa_psr_full_dev",
     "vqa_statevector", "vqa_sample_counts", "vqa_sample_counts_dev", "vqa_dead_parameters", "vqa_psr_params_dev",
-    "vqa_psr_full_noalloc_dev",
+    "vqa_psr_full_noalloc_dev", "vqa_mse_stats_workspace", "vqa_mse_stats_dev",
 )
 
 
@@ -66,6 +66,9 @@ def lib():
     L.vqa_psr_full_dev.argtypes = [vp, C.c_int, vp, dp, dp, C.c_int, ip, C.c_int, C.c_double,
                                    vp, C.c_int, C.c_int, dp, dp]
     L.vqa_psr_full_noalloc_dev.argtypes = L.vqa_psr_full_dev.argtypes
+    L.vqa_mse_stats_workspace.argtypes = [C.c_int64, C.c_int]
+    L.vqa_mse_stats_dev.argtypes = [C.c_int, vp, dp, dp, C.c_int64, C.c_int, dp, C.c_double, dp, dp, C.c_double,
+                                    C.c_int, C.c_uint64, C.c_int, C.c_double, C.c_int, dp, dp, dp, dp]
     L.vqa_statevector.argtypes = [vp, C.c_int, dp, dp, C.c_int, C.c_double, dp]
     L.vqa_psr_params_dev.argtypes = [vp, C.c_int, vp, dp, dp, C.c_int, ip, C.c_int, C.c_double, vp,
                                      vp, C.c_int, C.c_int, dp, dp]
@@ -74,8 +77,9 @@ def lib():
     L.vqa_sample_counts_dev.argtypes = [C.c_int, vp, dp, C.c_int, ip, C.c_int64, C.c_uint64, C.c_uint64, ip]
     for name in EXPORTS:
         fn = getattr(L, name)
-        if name not in ("vqa_last_error",):
+        if name not in ("vqa_last_error", "vqa_mse_stats_workspace"):
             fn.restype = C.c_int
+    L.vqa_mse_stats_workspace.restype = C.c_int64
     _lib = L
     return L
 

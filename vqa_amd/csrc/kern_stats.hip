@@ -1,0 +1,232 @@
+// Estimator epilogue of the regressor's parameter-shift oracles on the device.
+//
+// Input: the matrix of exact expectation values of a sweep, E[b, k] (b = sample of the
+// mini-batch, k = 0 unshifted, 2i+1 / 2i+2 = parameter i shifted by +-pi/2), the labels, the
+// scale parameter w and the shot budget.  Output: per gradient component the batch sums the
+// reference's oracles reduce to -- MSE_grad_eval (vqa/QNN/myQNNs_base.py:1346-1395) and MSE_iEval
+// with its variance estimators (1421-1596, 1205-1316) -- so that only O(P) numbers leave the GPU.
+// One hand-written pass over the matrix replaces the reference's (parameter) x (shift) x (sample)
+// Python loop nest around its per-sample estimators (799-905):
+//   mode 0  exact        every estimate is the exact value (min_approx_shots == -10, 874-882)
+//   mode 1  CLT          estimate = E + z sqrt((1 - E^2) / n), z standard normal (892-905)
+//   mode 2  finite shots estimate = (n - 2 k) / n, k ~ Binomial(n, (1 - E) / 2)   (715-738)
+//   mode 3  given        the caller supplies the estimates (tests of the algebra)
+// Shots of instance (b, i): n = floor(shots[i] * weight[b]) (1367, 1383); the unshifted
+// evaluation uses n_shots0.  Random numbers: Philox streams named by (seed, b * K + column), so
+// results do not depend on the launch shape.  Unbiased powers: 843-847.
+//
+// Layout of the work: a workgroup takes a tile of samples; its threads are gradient components
+// (thread t: parameters t, t + 256, ...), so a wave reads consecutive (E+, E-) pairs of one row.
+// Per-tile partial sums go to the caller's workspace and a second kernel adds the tiles in
+// order: the result does not depend on scheduling.
+#include "philox.h"
+#include "vqa_core.h"
+
+namespace vqa {
+
+namespace {
+
+constexpr int kT = 256;
+constexpr int kTile = 32;   // samples per workgroup
+constexpr int kQ = 8;       // sums per gradient component
+
+struct StatsArgs {
+    const double* E;        // [B, K]
+    const double* est;      // mode 3: [B, K]
+    const double* y;        // [B]
+    const double* shots;    // [P + 1] (scale parameter last); unused in mode 0
+    const double* weight;   // [B] or null (all ones)
+    int64_t B;
+    int P;
+    double w, n_shots0, n0;
+    int mode, want_var, second_order;
+    uint64_t seed;
+    double* partial;        // [tiles, P + 1, kQ]
+    double* m0;             // [B] estimates of the unshifted value, or null
+    double* gd;             // [P + 1, B] per-sample gradient terms, or null
+};
+
+// per-sample quantities of the unshifted evaluation, shared by every component (LDS)
+struct Base {
+    double EX, resid, err2, alt_err2, var_err, wt, y, pad;
+};
+
+__device__ __forceinline__ double ub2(double M, double n) { return (n / (n - 1.0)) * M * M - 1.0 / (n - 1.0); }
+
+__device__ __forceinline__ double estimate1(const StatsArgs& a, double e, double n, uint64_t row) {
+    if (a.mode == 0) return e;
+    Philox rng;
+    rng.init(a.seed, 0, row);
+    if (a.mode == 1) {
+        double z0, z1;
+        rng.normal2(z0, z1);
+        return e + z0 * sqrt(fmax(1.0 - e * e, 0.0) / n);
+    }
+    const int64_t k = binomial(rng, (int64_t)n, fmin(fmax(0.5 * (1.0 - e), 0.0), 1.0));
+    return (n - 2.0 * (double)k) / n;
+}
+
+__global__ __launch_bounds__(kT) void k_mse_stats(StatsArgs a) {
+    __shared__ Base sb[kTile];
+    const int K = 2 * a.P + 1;
+    const int64_t b0 = (int64_t)blockIdx.x * kTile;
+    const int nb = (int)min((int64_t)kTile, a.B - b0);
+    const int tid = threadIdx.x;
+    const double w = a.w, w2 = w * w;
+    const bool so = a.second_order && a.n0 != 0.0;
+    double* part = a.partial + (size_t)blockIdx.x * (a.P + 1) * kQ;
+    // ---- the unshifted evaluation of every sample of the tile; the scale parameter's sums ----
+    double q[kQ];
+#pragma unroll
+    for (int k = 0; k < kQ; ++k) q[k] = 0.0;
+    if (tid < nb) {
+        const int64_t b = b0 + tid;
+        const double y = a.y[b], wt = a.weight ? a.weight[b] : 1.0;
+        const double n = floor(a.n_shots0 * wt);
+        const double e = a.E[b * K];
+        const double EX = a.mode == 3 ? a.est[b * K] : estimate1(a, e, n, (uint64_t)(b * K));
+        double EX_2, EX_3, EX_4, var_0;
+        if (a.mode == 0) {
+            EX_2 = EX * EX; EX_3 = EX_2 * EX; EX_4 = EX_2 * EX_2;
+            var_0 = 1.0 - EX_2;
+        } else {
+            EX_2 = ub2(EX, n);
+            EX_3 = (n / (n - 1.0)) * (n / (n - 2.0)) * EX * EX * EX - (3.0 * n - 2.0) / (n - 1.0) / (n - 2.0) * EX;
+            EX_4 = (n / (n - 1.0)) * (n / (n - 2.0)) * (n / (n - 3.0)) * EX * EX * EX * EX -
+                   ((n / (n - 1.0)) * ((6.0 * n - 8.0) / (n - 2.0)) * EX * EX - 3.0 / (n - 1.0)) / (n - 3.0);
+            var_0 = n / (n - 1.0) * (1.0 - EX * EX);
+        }
+        Base s;
+        s.EX = EX;
+        s.y = y;
+        s.wt = wt;
+        s.resid = (w * EX - y) * w;
+        s.err2 = y * y - 2.0 * w * y * EX + w2 * EX_2;
+        s.alt_err2 = (y - w * EX) * (y - w * EX);
+        s.var_err = w2 * var_0;
+        s.pad = 0.0;
+        sb[tid] = s;
+        if (a.m0) a.m0[b] = EX;
+        const double A = -2.0 * y, Bc = 2.0 * w;
+        const double gd = 2.0 * (-y * EX + w * EX_2);
+        q[0] = gd;
+        q[1] = gd * gd;
+        if (a.want_var) {
+            double est = A * A + 4.0 * A * Bc * EX + (4.0 * Bc * Bc - A * A) * EX_2 - 4.0 * A * Bc * EX_3 - 4.0 * Bc * Bc * EX_4;
+            double alt = (A + 2.0 * Bc * EX) * (A + 2.0 * Bc * EX) * var_0;
+            if (so) {
+                est += 2.0 * Bc * Bc * (1.0 - 2.0 * EX + EX_2) / (a.n0 - 1.0);
+                alt += 2.0 * Bc * Bc * var_0 * var_0 / (a.n0 - 1.0);
+            }
+            q[2] = est;
+            q[4] = alt;
+            q[6] = A * A * EX_2 + 2.0 * A * Bc * EX_3 + Bc * Bc * EX_4;
+        }
+        if (a.gd) a.gd[(size_t)a.P * a.B + b] = gd;
+    }
+    __syncthreads();
+    // the scale parameter's sums over the tile, in sample order (thread 0; nb <= 32 values each)
+    {
+        __shared__ double red[kTile][kQ];
+        if (tid < nb) {
+#pragma unroll
+            for (int k = 0; k < kQ; ++k) red[tid][k] = q[k];
+        }
+        __syncthreads();
+        if (tid < kQ) {
+            double s = 0.0;
+            for (int j = 0; j < nb; ++j) s += red[j][tid];
+            part[(size_t)a.P * kQ + tid] = s;
+        }
+    }
+    // ---- the circuit parameters: thread = component, loop over the tile's samples ----
+    for (int i = tid; i < a.P; i += kT) {
+#pragma unroll
+        for (int k = 0; k < kQ; ++k) q[k] = 0.0;
+        const double shots_i = a.mode == 0 ? 0.0 : a.shots[i];
+        for (int j = 0; j < nb; ++j) {
+            const int64_t b = b0 + j;
+            const Base s = sb[j];
+            const double* ep = a.E + b * K + 1 + 2 * i;
+            const double2 e = make_double2(ep[0], ep[1]);   // (E+, E-)
+            double Mp, Mm;
+            const double n = floor(shots_i * s.wt);
+            if (a.mode == 0) {
+                Mp = e.x; Mm = e.y;
+            } else if (a.mode == 3) {
+                Mp = a.est[b * K + 1 + 2 * i];
+                Mm = a.est[b * K + 2 + 2 * i];
+            } else if (a.mode == 1) {
+                Philox rng;
+                rng.init(a.seed, 0, (uint64_t)(b * K + 1 + 2 * i));
+                double z0, z1;
+                rng.normal2(z0, z1);
+                Mp = e.x + z0 * sqrt(fmax(1.0 - e.x * e.x, 0.0) / n);
+                Mm = e.y + z1 * sqrt(fmax(1.0 - e.y * e.y, 0.0) / n);
+            } else {
+                Philox rng;
+                rng.init(a.seed, 0, (uint64_t)(b * K + 1 + 2 * i));
+                const int64_t kp = binomial(rng, (int64_t)n, fmin(fmax(0.5 * (1.0 - e.x), 0.0), 1.0));
+                const int64_t km = binomial(rng, (int64_t)n, fmin(fmax(0.5 * (1.0 - e.y), 0.0), 1.0));
+                Mp = (n - 2.0 * (double)kp) / n;
+                Mm = (n - 2.0 * (double)km) / n;
+            }
+            const double d = Mp - Mm, gd = s.resid * d;
+            q[0] += gd;
+            q[1] += gd * gd;
+            if (a.want_var) {
+                const double EXp_2 = ub2(Mp, n), EXm_2 = ub2(Mm, n);
+                const double var_p = n / (n - 1.0) * (1.0 - Mp * Mp), var_m = n / (n - 1.0) * (1.0 - Mm * Mm);
+                const double dp2 = EXp_2 - 2.0 * Mp * Mm + EXm_2;
+                const double var_dpdt = w2 * (var_p + var_m);
+                const double extra = so ? s.var_err * var_dpdt / a.n0 : 0.0;
+                q[2] += s.err2 * var_dpdt + extra;        // E_x[Var] main form, shifted part
+                q[3] += s.var_err * w2 * dp2;             //               ... unshifted part
+                q[4] += s.alt_err2 * var_dpdt + extra;    // the forms used when a mean comes out negative
+                q[5] += s.var_err * w2 * d * d;
+                q[6] += s.err2 * w2 * dp2;                // second moment of the per-sample gradient term
+            }
+            if (a.gd) a.gd[(size_t)i * a.B + b] = gd;
+        }
+#pragma unroll
+        for (int k = 0; k < kQ; ++k) part[(size_t)i * kQ + k] = q[k];
+    }
+}
+
+// out[c, k] = sum over tiles (in order) of partial[tile, c, k]
+__global__ __launch_bounds__(kT) void k_mse_stats_finish(const double* partial, int n_tiles, int n_rows, double* out) {
+    const int idx = blockIdx.x * kT + threadIdx.x;
+    if (idx >= n_rows * kQ) return;
+    double s = 0.0;
+    for (int t = 0; t < n_tiles; ++t) s += partial[(size_t)t * n_rows * kQ + idx];
+    out[idx] = s;
+}
+
+}  // namespace
+
+size_t mse_stats_workspace_bytes(int64_t B, int P) {
+    const int64_t tiles = (B + kTile - 1) / kTile;
+    return (size_t)tiles * (size_t)(P + 1) * kQ * sizeof(double);
+}
+
+int mse_stats_launch(hipStream_t stream, const double* d_E, const double* d_est, int64_t B, int P, const double* d_y,
+                     double w, const double* d_shots, const double* d_weight, double n_shots0, int mode, uint64_t seed,
+                     int want_var, double n0, int second_order, double* d_workspace, double* d_out, double* d_m0,
+                     double* d_gd) {
+    if (B <= 0) return VQA_OK;
+    StatsArgs a;
+    a.E = d_E; a.est = d_est; a.y = d_y; a.shots = d_shots; a.weight = d_weight;
+    a.B = B; a.P = P; a.w = w; a.n_shots0 = n_shots0; a.n0 = n0;
+    a.mode = mode; a.want_var = want_var; a.second_order = second_order; a.seed = seed;
+    a.partial = d_workspace; a.m0 = d_m0; a.gd = d_gd;
+    const int64_t tiles = (B + kTile - 1) / kTile;
+    hipLaunchKernelGGL(k_mse_stats, dim3((unsigned)tiles), dim3(kT), 0, stream, a);
+    VQA_HIP(hipGetLastError());
+    const int n = (P + 1) * kQ;
+    hipLaunchKernelGGL(k_mse_stats_finish, dim3((unsigned)((n + kT - 1) / kT)), dim3(kT), 0, stream, d_workspace, (int)tiles,
+                       P + 1, d_out);
+    VQA_HIP(hipGetLastError());
+    return VQA_OK;
+}
+
+}  // namespace vqa

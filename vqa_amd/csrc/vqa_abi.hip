@@ -810,6 +810,31 @@ int vqa_sample_counts(int device, const double* probs, int n_outcomes, const int
     return VQA_OK;
 }
 
+int64_t vqa_mse_stats_workspace(int64_t B, int P) {
+    if (B < 0 || P < 0) return 0;
+    return (int64_t)mse_stats_workspace_bytes(B, P);
+}
+
+int vqa_mse_stats_dev(int device, void* stream, const double* d_expect, const double* d_estimates, int64_t B, int P,
+                      const double* d_y, double w, const double* d_shots, const double* d_weight, double n_shots0,
+                      int mode, uint64_t seed, int want_variances, double n0, int second_order, double* d_workspace,
+                      double* d_out_sums, double* d_out_m0, double* d_out_grad_data) {
+    if (B < 0 || P < 0) VQA_FAIL(VQA_EINVAL, "B and P must be >= 0");
+    if (mode < 0 || mode > 3) VQA_FAIL(VQA_EINVAL, "mode must be 0 (exact), 1 (CLT), 2 (finite shots) or 3 (given estimates)");
+    if (!d_out_sums) VQA_FAIL(VQA_EINVAL, "out_sums is NULL");
+    if (B == 0) return VQA_OK;
+    if (!d_expect || !d_y || !d_workspace) VQA_FAIL(VQA_EINVAL, "expect, y and workspace must not be NULL");
+    if (mode == 3 && !d_estimates) VQA_FAIL(VQA_EINVAL, "mode 3 needs the estimates");
+    if (mode != 0 && !d_shots) VQA_FAIL(VQA_EINVAL, "modes 1 to 3 need the shot list");
+    if (mode == 0 && want_variances) VQA_FAIL(VQA_EINVAL, "the variance estimators need estimates from shots (modes 1 to 3)");
+    int count = 0;
+    VQA_HIP(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) VQA_FAIL(VQA_ENODEVICE, "device %d out of range (%d visible)", device, count);
+    VQA_HIP(hipSetDevice(device));
+    return mse_stats_launch((hipStream_t)stream, d_expect, d_estimates, B, P, d_y, w, d_shots, d_weight, n_shots0, mode, seed,
+                            want_variances, n0, second_order, d_workspace, d_out_sums, d_out_m0, d_out_grad_data);
+}
+
 int vqa_statevector(vqa_circuit* c, int device, const double* theta, const double* input_row,
                     int shift_param, double shift_val, double* out_state) {
     if (!c) VQA_FAIL(VQA_EINVAL, "circuit handle is NULL");

@@ -203,6 +203,13 @@ int fill_dead_rows(hipStream_t stream, double* d_out, int64_t n_samples, int K, 
 int sample_counts_launch(hipStream_t stream, const double* d_probs, int M, const int64_t* d_shots, int64_t E,
                          uint64_t seed, uint64_t stream_id, int64_t* d_counts);
 
+// estimator epilogue of the regressor's oracles (kern_stats.hip)
+size_t mse_stats_workspace_bytes(int64_t B, int P);
+int mse_stats_launch(hipStream_t stream, const double* d_E, const double* d_est, int64_t B, int P, const double* d_y,
+                     double w, const double* d_shots, const double* d_weight, double n_shots0, int mode, uint64_t seed,
+                     int want_var, double n0, int second_order, double* d_workspace, double* d_out, double* d_m0,
+                     double* d_gd);
+
 // Working memory of a call: the per-device workspace owned by the library (grown on demand, never
 // shrunk; users on different streams are ordered by an event) or, for a call with a fixed region,
 // the next `bytes` of that region (VQA_EUNSUPPORTED when it does not hold them).

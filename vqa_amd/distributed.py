@@ -63,7 +63,13 @@ def sharded_mse_gradient(circuit, theta, inputs, y, w, obs, n_global=None, group
     if isinstance(e, np.ndarray):
         e = torch.from_numpy(e)
     y_t = y if isinstance(y, torch.Tensor) else torch.from_numpy(np.asarray(y, np.float64)).to(e.device)
-    sums = mse_gradient_sums(e, y_t, w)
+    if e.is_cuda:
+        # the library's estimator epilogue: one pass over the matrix, fixed summation order
+        from .stats import GD, mse_stats
+
+        sums = torch.from_numpy(np.ascontiguousarray(mse_stats(e, y_t, w)[0][:, GD])).to(e.device)
+    else:
+        sums = mse_gradient_sums(e, y_t, w)
     distributed = dist.is_available() and dist.is_initialized()
     if n_global is None:
         count = torch.tensor([float(e.shape[0])], dtype=torch.float64, device=e.device)

@@ -629,12 +629,11 @@ class myQNN_base:
         B, K = int(E.shape[0]), int(E.shape[1])
         w = float(params[-1])
         if hasattr(E, "detach"):
-            import torch
+            from .stats import GD, mse_stats
 
-            y = torch.from_numpy(np.ascontiguousarray(y_eval, dtype=np.float64)).to(E.device)
-            sums = mse_gradient_sums(E, y, w)
-            grad = (sums / B).cpu().numpy()
-            e0 = E[:, 0].cpu().numpy()
+            sums, m0, _ = mse_stats(E, y_eval, w, want_m0=True)
+            grad = sums[:, GD] / B
+            e0 = m0.cpu().numpy()
         else:
             grad = mse_gradient_sums(E, np.asarray(y_eval, dtype=float), w) / B
             e0 = E[:, 0]
@@ -666,58 +665,35 @@ class myQNN_base:
         E = self._psr_all(params, eval_ind, keep_on_device=True)
         if not hasattr(E, "detach"):
             return None
-        import torch
+        from .stats import CLT, GD, SHOTS, mse_stats
 
         B, K = int(E.shape[0]), int(E.shape[1])
         P = self.n_c_params
         seed = int(np.random.randint(0, 2 ** 31 - 1))
         w = float(params[-1])
-        y = torch.from_numpy(np.ascontiguousarray(y_eval, dtype=np.float64)).to(E.device)
-        n = torch.from_numpy(n_all).to(E.device)                        # [P+1, B]
-        n_inst = torch.empty((B, K), dtype=torch.float64, device=E.device)
-        n_inst[:, 0] = n[-1]
-        n_inst[:, 1::2] = n[:P].T
-        n_inst[:, 2::2] = n[:P].T
-        M = self._device_estimates(E, n_inst, sampled, seed)
-        M0 = M[:, 0]
-        n0 = n[-1]
-        M0sq = (n0 / (n0 - 1.0)) * M0 * M0 - 1.0 / (n0 - 1.0)           # unbiased square, myQNNs_base.py:843
-        resid = (w * M0 - y) * w
-        grad = torch.empty(P + 1, dtype=torch.float64, device=E.device)
-        grad[:P] = (resid[:, None] * (M[:, 1::2] - M[:, 2::2])).mean(0)
-        grad[P] = (2.0 * (-y * M0 + w * M0sq)).mean()
+        n_list = np.asarray(n_shots_list, dtype=float)
+        sums, m0, _ = mse_stats(E, y_eval, w, shots=n_list, weight=wt_dist, n_shots0=n_list[-1],
+                                mode=SHOTS if sampled else CLT, seed=seed, want_m0=True)
         self.circuit_counter[0] += B * K
         self.call_counter[0] += (2 if sampled else 1) * B * K           # a sampled state counts twice (myQNNs_base.py:722, 1033)
         self.shots_counter[0] += int(n_all[-1].sum() + 2 * n_all[:P].sum())
-        self.cache_train_pred = (w * M0).cpu().numpy()
+        self.cache_train_pred = w * m0.cpu().numpy()
         self.cache_y_train_eval = y_eval
         out = np.zeros_like(params)
-        out[:] = grad.cpu().numpy()
+        out[:] = sums[:, GD] / B
         return out
-
-    def _device_estimates(self, E, n_inst, sampled, seed):
-        """One estimate of every exact value in E [B, K] from n_inst shots each, on E's device:
-        CLT deviates (myQNNs_base.py:895-900) or sampled means (715-738)."""
-        import torch
-
-        if sampled:
-            from .sampling import sample_z_means
-
-            return sample_z_means(E, n_inst.to(torch.int64), seed)
-        gen = torch.Generator(device=E.device)
-        gen.manual_seed(seed)
-        return E + torch.randn(E.shape, dtype=torch.float64, device=E.device, generator=gen) * torch.sqrt((1.0 - E * E) / n_inst)
 
     def _ieval_on_device(self, params, n_shots_list, wt_dist, eval_ind, y_eval, min_approx, size, Max_n_shots0,
                          second_order, _estimates=None):
         """MSE_iEval (myQNNs_base.py:1421-1596, the branches without the -10 debug mode) with every
-        per-sample array kept on the GPU: the estimator polynomials and their batch means, including
-        the alternatives the reference falls back to when a mean comes out negative (1242-1248,
-        1274-1286, 1314-1315), are evaluated for all parameters at once, and only the five vectors
-        of P+1 numbers come back ('grad_data_list' stays a device tensor).  The reference hands the
-        PARTLY filled (P+1, B) matrix of per-sample gradients to its batch-variance estimator
-        (1488, 1578): row sums are accumulated in that order here.  None when the circuit does not
-        compute on a GPU or the batch mixes CLT and sampled estimates."""
+        per-sample array kept on the GPU: one kernel pass over the sweep's matrix (vqa_mse_stats_dev)
+        draws the estimates, evaluates the estimator polynomials -- including the alternatives the
+        reference falls back to when a mean comes out negative (1242-1248, 1274-1286, 1314-1315) --
+        and sums them over the batch; the P+1 rows of sums are finished here ('grad_data_list' stays a
+        device tensor).  The reference hands the PARTLY filled (P+1, B) matrix of per-sample
+        gradients to its batch-variance estimator (1488, 1578): row sums are accumulated in that
+        order here.  None when the circuit does not compute on a GPU or the batch mixes CLT and
+        sampled estimates.  _estimates (tests): the [B, 2P+1] matrix of estimates to use."""
         P = self.n_c_params
         n_list = np.asarray(n_shots_list, dtype=float)
         n0 = float(n_list[-1])
@@ -737,88 +713,46 @@ class myQNN_base:
         E = self._psr_all(params, eval_ind, keep_on_device=True)
         if not hasattr(E, "detach"):
             return None
-        import torch
+        from .stats import ALT_0, ALT_I, CLT, EV_0, EV_I, GD, GD2, GD_SQ, GIVEN, SHOTS, mse_stats
 
-        dev = E.device
         B, K = int(E.shape[0]), int(E.shape[1])
         w = float(params[-1])
-        y = torch.from_numpy(np.ascontiguousarray(y_eval, dtype=np.float64)).to(dev)
-        nb = torch.from_numpy(nb_h).to(dev)
-        ni = torch.from_numpy(ni_h).to(dev)
-        n_inst = torch.empty((B, K), dtype=torch.float64, device=dev)
-        n_inst[:, 0] = nb
-        n_inst[:, 1::2] = ni.T
-        n_inst[:, 2::2] = ni.T
         seed = int(np.random.randint(0, 2 ** 31 - 1))
-        M = self._device_estimates(E, n_inst, sampled, seed) if _estimates is None else _estimates
-        # unshifted circuit: unbiased powers 1..4 (myQNNs_base.py:843-847) and sample variance (902)
-        EX = M[:, 0]
-        n = nb
-        EX_2 = (n / (n - 1.0)) * EX ** 2 - 1.0 / (n - 1.0)
-        EX_3 = (n / (n - 1.0)) * (n / (n - 2.0)) * EX ** 3 - (3.0 * n - 2.0) / (n - 1.0) / (n - 2.0) * EX
-        EX_4 = (n / (n - 1.0)) * (n / (n - 2.0)) * (n / (n - 3.0)) * EX ** 4 \
-            - ((n / (n - 1.0)) * ((6.0 * n - 8.0) / (n - 2.0)) * EX ** 2 - 3.0 / (n - 1.0)) / (n - 3.0)
-        var_0 = n / (n - 1.0) * (1.0 - EX ** 2)
-        a, b = -2.0 * y, 2.0 * w
-        so = bool(second_order and n0)
-        gd_last = 2.0 * (-y * EX + w * EX_2)                                   # [B]
-        # scale parameter: conditional variance, its fallback, and the batch variance
-        est = a ** 2 + 4.0 * a * b * EX + (4.0 * b ** 2 - a ** 2) * EX_2 - 4.0 * a * b * EX_3 - 4.0 * b ** 2 * EX_4
-        if so:
-            est = est + 2.0 * b ** 2 * (1.0 - 2.0 * EX + EX_2) / (n0 - 1.0)
-        ev_last = float(est.mean())
-        if ev_last < 0:
-            est = (a + 2.0 * b * EX) ** 2 * var_0
-            if so:
-                est = est + 2.0 * b ** 2 * var_0 ** 2 / (n0 - 1.0)
-            ev_last = float(est.mean())
+        mode = GIVEN if _estimates is not None else SHOTS if sampled else CLT
+        S, m0, gd = mse_stats(E, y_eval, w, shots=n_list, weight=wt_dist, n_shots0=n_shots0, mode=mode, seed=seed,
+                              want_variances=True, n0=n0, second_order=bool(second_order and n0), estimates=_estimates,
+                              want_m0=True, want_grad_data=True)
         N_all = float((P + 1) * B)
 
         def batch_var(sum_gd2, S1, S2):
             """_estimate_MSEgrad_Var_condMean on sums: S1, S2 = sum and sum of squares of the matrix so far."""
             v = sum_gd2 / size - (S1 ** 2 - S2) / (size * (size - 1.0))
             alt = (S2 - S1 ** 2 / N_all) / (N_all - 1.0)                        # np.var(matrix, ddof=1), zero rows included
-            return torch.where(v < 0, alt, v)
+            return np.where(v < 0, alt, v)
 
-        s1_last, s2_last = gd_last.sum(), (gd_last ** 2).sum()
-        gd2_last = (a ** 2 * EX_2 + 2.0 * a * b * EX_3 + b ** 2 * EX_4).sum()
-        b_last = float(batch_var(gd2_last, s1_last, s2_last))
         grad = np.zeros_like(params, dtype=float)
         gvar_b, gvar_EV, gvar_EVi, gvar_EV0 = (np.zeros_like(grad) for _ in range(4))
-        grad[-1] = float(gd_last.mean())
+        grad[:] = S[:, GD] / B
+        # scale parameter: conditional variance (or its fallback) and the batch variance
+        ev_last = S[P, EV_I] / B
+        if ev_last < 0:
+            ev_last = S[P, ALT_I] / B
         gvar_EV[-1] = gvar_EV0[-1] = ev_last
-        gvar_b[-1] = b_last
-        gd = torch.empty((P + 1, B), dtype=torch.float64, device=dev)
-        gd[P] = gd_last
+        gvar_b[-1] = float(batch_var(S[P, GD2], S[P, GD], S[P, GD_SQ]))
         if P:
-            Mp, Mm = M[:, 1::2].T, M[:, 2::2].T                                # [P, B]
-            EXp_2 = (ni / (ni - 1.0)) * Mp ** 2 - 1.0 / (ni - 1.0)
-            EXm_2 = (ni / (ni - 1.0)) * Mm ** 2 - 1.0 / (ni - 1.0)
-            var_p = ni / (ni - 1.0) * (1.0 - Mp ** 2)
-            var_m = ni / (ni - 1.0) * (1.0 - Mm ** 2)
-            gd[:P] = ((w * EX - y) * w)[None, :] * (Mp - Mm)
-            w2 = w * w
-            err2 = (y ** 2 - 2.0 * w * y * EX + w2 * EX_2)[None, :]
-            dp2 = EXp_2 - 2.0 * Mp * Mm + EXm_2
-            var_dpdt = w2 * (var_p + var_m)
-            var_err = (w2 * var_0)[None, :]
-            extra = var_err * var_dpdt / n0 if so else 0.0
-            EV_i = (err2 * var_dpdt + extra).mean(dim=1)
-            EV_0 = (var_err * w2 * dp2).mean(dim=1)
-            mcv = EV_i + EV_0
-            EV_0 = torch.where(EV_0 < 0, (var_err * w2 * (Mp - Mm) ** 2).mean(dim=1), EV_0)
-            EV_i = torch.where(EV_i < 0, (((y - w * EX) ** 2)[None, :] * var_dpdt + extra).mean(dim=1), EV_i)
-            mcv = torch.where(mcv < 0, EV_i + EV_0, mcv)
-            rs1, rs2 = gd[:P].sum(dim=1), (gd[:P] ** 2).sum(dim=1)
-            S1 = s1_last + torch.cumsum(rs1, 0)
-            S2 = s2_last + torch.cumsum(rs2, 0)
-            gd2 = (err2 * w2 * dp2).sum(dim=1)
-            packed = torch.stack([gd[:P].mean(dim=1), mcv, EV_i, EV_0, batch_var(gd2, S1, S2)]).cpu().numpy()
-            grad[:P], gvar_EV[:P], gvar_EVi[:P], gvar_EV0[:P], gvar_b[:P] = packed
+            ev_i, ev_0 = S[:P, EV_I] / B, S[:P, EV_0] / B
+            mcv = ev_i + ev_0
+            ev_0 = np.where(ev_0 < 0, S[:P, ALT_0] / B, ev_0)
+            ev_i = np.where(ev_i < 0, S[:P, ALT_I] / B, ev_i)
+            mcv = np.where(mcv < 0, ev_i + ev_0, mcv)
+            S1 = S[P, GD] + np.cumsum(S[:P, GD])
+            S2 = S[P, GD_SQ] + np.cumsum(S[:P, GD_SQ])
+            gvar_EV[:P], gvar_EVi[:P], gvar_EV0[:P] = mcv, ev_i, ev_0
+            gvar_b[:P] = batch_var(S[:P, GD2], S1, S2)
         self.circuit_counter[0] += B * K
         self.call_counter[0] += (2 if sampled else 1) * B * K
         self.shots_counter[0] += int(nb_h.sum() + 2 * ni_h.sum())
-        self.cache_train_pred = (w * EX).cpu().numpy()
+        self.cache_train_pred = w * m0.cpu().numpy()
         self.cache_y_train_eval = y_eval
         return {"grad": grad, "gvar_list_EV": gvar_EV, "gvar_list_EVi": gvar_EVi, "gvar_list_EV0": gvar_EV0,
                 "gvar_list_b": gvar_b, "grad_data_list": gd}
