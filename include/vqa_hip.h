@@ -303,6 +303,27 @@ int vqa_mse_stats_dev(int device, void* stream, const double* d_expect, const do
                       double* d_out_sums, double* d_out_m0, double* d_out_grad_data);
 
 /*
+ * Gradient and variance estimates of the oracles with independent random shot allocation
+ * (MSE_iEval_iRandom: vqa/QNN/myQNNs_base.py:1619-1666; classifier, partial MSE:
+ * vqa/QNN/myQNNs_classifier.py:1017-1053), from the exact values of a ragged instance list.
+ * A row r is one (gradient component, sample that received shots); rows of component i are
+ * seg[i] .. seg[i+1]; d_expect[(3 r + v) * n_obs + col] holds the exact value of the row's
+ * unshifted (v = 0) and shifted (v = 1: +pi/2, 2: -pi/2) circuit as computed by
+ * vqa_eval_batch_dev on the list in that order.  kind 0: <Z0> (col 0), labels d_y[r], scale w;
+ * with has_scale the last component is the scale parameter, whose rows use twice d_shots[r]
+ * outcomes of the unshifted circuit (1642-1653).  kind 1: class probabilities, col = d_label[r].
+ * The reference keeps the raw outcomes of d_shots[r] shots of each circuit; the kernel draws the
+ * counts of their joint outcomes instead (same distribution; Philox keyed by seed, one stream
+ * per row) and writes d_out[2 i] = the gradient estimate (1652, 1662; classifier 1049) and
+ * d_out[2 i + 1] = the sample variance of the per-shot products (1599-1617; classifier 1002-1015).
+ * d_n_list[i]: the component's total shots; M_tot: number of training samples.
+ */
+int vqa_irandom_stats_dev(int device, void* stream, const double* d_expect, int n_obs,
+                          const int32_t* d_label, const double* d_y, const int64_t* d_shots,
+                          const int32_t* d_seg, const double* d_n_list, int n_components, int kind,
+                          int has_scale, double w, double M_tot, uint64_t seed, double* d_out);
+
+/*
  * Final state of ONE instance, interleaved (re, im) doubles, 2 * 2^n values,
  * host pointer.  For plumbing tests of the per-sample circuit.run(x) shim
  * (vqa/QNN/myQNNs_base.py:913); not a hot-path call.

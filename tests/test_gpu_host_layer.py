@@ -167,6 +167,42 @@ def test_classifier_device_statistics_gradient(unbias, partial):
     assert np.all(gd.std(axis=0) < 1.8 * sd) and np.all(gd.std(axis=0) > sd / 1.8)
 
 
+@pytest.mark.parametrize("cls", [myQNN_base, myQNN_classifier])
+def test_device_irandom_statistics(cls):
+    """MSE_iEval_iRandom with the outcome counts of every (component, sample) row drawn and reduced
+    by the device kernel: the host path's counters and shot totals, gradient estimates with the host
+    path's mean and scatter, variance estimates with the host path's mean."""
+    kw = dict(class_unbias=True) if cls is myQNN_classifier else {}
+    (g, p), (o, _) = pair(create_ibm_HEA_ansatz, 5, 1, cls, n_train=24, **kw)
+    g.device_statistics = True
+    if cls is myQNN_base:
+        g.min_approx_shots = o.min_approx_shots = -1
+    shots = np.full(g.n_params, 600)
+    shots[0] = 900
+    np.random.seed(5)
+    a = g.MSE_iEval_iRandom(p, shots)
+    np.random.seed(5)
+    b = o.MSE_iEval_iRandom(p, shots)
+    assert set(a) == set(b) and a["grad"].shape == b["grad"].shape
+    assert (g.shots_counter[0], g.call_counter[0], g.circuit_counter[0]) == \
+           (o.shots_counter[0], o.call_counter[0], o.circuit_counter[0])
+    R = 80
+    gd = [g.MSE_iEval_iRandom(p, shots) for _ in range(R)]
+    gh = [o.MSE_iEval_iRandom(p, shots) for _ in range(R)]
+    for key, scatter in (("grad", True), ("gvar_list", False)):
+        d = np.array([r[key] for r in gd])
+        h = np.array([r[key] for r in gh])
+        sd = h.std(axis=0) + 1e-12
+        assert np.max(np.abs(d.mean(axis=0) - h.mean(axis=0)) / sd) < 6 * np.sqrt(2.0 / R), key
+        if scatter:
+            assert np.all(d.std(axis=0) < 1.8 * sd) and np.all(d.std(axis=0) > sd / 1.8)
+    # few shots: most samples receive none, rows are ragged per component
+    few = np.full(g.n_params, 7)
+    np.random.seed(6)
+    c = g.MSE_iEval_iRandom(p, few)
+    assert np.all(np.isfinite(c["grad"])) and np.all(np.isfinite(c["gvar_list"])) and np.all(c["gvar_list"] >= 0)
+
+
 @pytest.mark.parametrize("second_order,max_n0", [(True, True), (False, False)])
 def test_device_ieval_equals_host_algebra(second_order, max_n0):
     """MSE_iEval evaluated on the GPU (all parameters at once, fallbacks included) against the

@@ -202,6 +202,112 @@ __global__ __launch_bounds__(kT) void k_mse_stats_finish(const double* partial, 
     out[idx] = s;
 }
 
+// ---- independent random allocation (gCANS / Refoqus): MSE_iEval_iRandom ---------------------------
+// vqa/QNN/myQNNs_base.py:1619-1666 (regressor) and vqa/QNN/myQNNs_classifier.py:1017-1053
+// (classifier, partial MSE).  Per gradient component i the reference allocates shots to samples
+// by a multinomial draw, evaluates the unshifted and the two shifted circuits of every sample
+// that received shots, keeps the raw outcomes and forms (a) the gradient estimate from the
+// outcome sums and (b) the sample variance of the per-shot products, the k-th shots of the three
+// circuits taken together.  The three outcome sequences are independent, so the counts of the
+// joint outcomes of a (component, sample) row are multinomial with product probabilities: the
+// kernel draws those counts (a chain of binomials) instead of materialising shots, which gives
+// the same distribution of every quantity the reference computes.
+// A row is (component, sample): expect[(3 r + v) * n_obs + col], v = 0 unshifted, 1 / 2 shifted;
+// rows of one component are contiguous, seg[i] .. seg[i + 1].  kind 0: Z0 outcomes +-1 of the
+// regressor (col 0; the last component is the scale parameter, whose rows use twice their shots,
+// split in halves: 1642-1653); kind 1: 'the true class was read' outcomes 1 / 0 of the classifier
+// (col = the row's label).  One workgroup per component; fixed-order reductions.
+struct IRandomArgs {
+    const double* expect;
+    int n_obs;
+    const int32_t* label;     // [R] (kind 1)
+    const double* y;          // [R] (kind 0)
+    const int64_t* shots;     // [R] shots of the row (before doubling, scale rows)
+    const int32_t* seg;       // [C + 1]
+    const double* n_list;     // [C] total shots of each component
+    int C, kind, has_scale;
+    double w, M_tot;
+    uint64_t seed;
+    double* out;              // [C, 2]: gradient, variance
+};
+
+__global__ __launch_bounds__(kT) void k_irandom_stats(IRandomArgs a) {
+    __shared__ double red[4][kT];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const int r0 = a.seg[c], r1 = a.seg[c + 1];
+    const double n = a.n_list[c], w = a.w;
+    const bool scale = a.has_scale && c == a.C - 1;
+    double acc[4] = { 0.0, 0.0, 0.0, 0.0 };   // gradient terms, sum g, sum g^2, shots
+    for (int r = r0 + tid; r < r1; r += kT) {
+        const int col = a.kind == 1 ? a.label[r] : 0;
+        const double e0 = a.expect[(size_t)(3 * (size_t)r + 0) * a.n_obs + col];
+        const double ep = a.expect[(size_t)(3 * (size_t)r + 1) * a.n_obs + col];
+        const double em = a.expect[(size_t)(3 * (size_t)r + 2) * a.n_obs + col];
+        const int64_t s = a.shots[r];
+        Philox rng;
+        rng.init(a.seed, 1, (uint64_t)r);
+        // probability of the outcome that is counted: -1 (kind 0), success (kind 1)
+        auto pr = [&](double e) { return fmin(fmax(a.kind == 0 ? 0.5 * (1.0 - e) : e, 0.0), 1.0); };
+        const double p0 = pr(e0), pp = pr(ep), pm = pr(em);
+        if (scale) {
+            // 2 s outcomes of the unshifted circuit, halves paired shot by shot: g = 2 (w o1 - y) o2
+            const double y = a.y[r];
+            const int64_t k1 = binomial(rng, s, p0);                 // o1 = -1
+            const int64_t k2a = binomial(rng, k1, p0);               // o2 = -1 where o1 = -1
+            const int64_t k2b = binomial(rng, s - k1, p0);           // o2 = -1 where o1 = +1
+            const double outsum = (double)(s - 2 * k1) + (double)(s - 2 * (k2a + k2b));
+            const double n_eval = 2.0 * (double)s;
+            acc[0] += w * (outsum * outsum - n_eval) / (2.0 * n * (n - 1.0) / a.M_tot + n) - y * outsum / n;
+            const double gm = 2.0 * (-w - y), gp = 2.0 * (w - y);   // (w o1 - y) * 2 for o1 = -1 / +1
+            // o2 = -1 flips the sign
+            const double c_mm = (double)k2a, c_mp = (double)(k1 - k2a), c_pm = (double)k2b, c_pp = (double)(s - k1 - k2b);
+            acc[1] += gm * (c_mp - c_mm) + gp * (c_pp - c_pm);
+            acc[2] += gm * gm * (double)k1 + gp * gp * (double)(s - k1);
+            acc[3] += (double)s;
+        } else {
+            const int64_t k0 = binomial(rng, s, p0);                 // counted outcome of the unshifted circuit
+            const int64_t kpa = binomial(rng, k0, pp), kpb = binomial(rng, s - k0, pp);
+            // of each (o0, o+) group, the shots whose o- is the counted outcome
+            const int64_t kma = binomial(rng, kpa, pm), kmb = binomial(rng, k0 - kpa, pm);
+            const int64_t kmc = binomial(rng, kpb, pm), kmd = binomial(rng, s - k0 - kpb, pm);
+            const double sp = (double)(kpa + kpb), sm = (double)(kma + kmb + kmc + kmd), s0 = (double)k0, sd = (double)s;
+            // shots with o+ != o-: (o+ counted, o- not) and (o+ not, o- counted), per value of o0
+            const double d_a = (double)(kpa - kma), u_a = (double)kmb;      // o0 counted
+            const double d_b = (double)(kpb - kmc), u_b = (double)kmd;      // o0 not counted
+            if (a.kind == 0) {
+                const double y = a.y[r];
+                const double out0 = sd - 2.0 * s0, outp = sd - 2.0 * sp, outm = sd - 2.0 * sm;
+                acc[0] += (w * out0 / (n + n * (n - 1.0) / a.M_tot) - y / n) * (outp - outm) * w;
+                // g = (w o0 - y) w (o+ - o-); o+ - o- = -2 when only o+ is -1, +2 when only o- is -1
+                const double fm = (-w - y) * w, fp = (w - y) * w;        // o0 = -1 / +1
+                acc[1] += 2.0 * (fm * (u_a - d_a) + fp * (u_b - d_b));
+                acc[2] += 4.0 * (fm * fm * (u_a + d_a) + fp * fp * (u_b + d_b));
+            } else {
+                acc[0] += (s0 / (1.0 + (n - 1.0) / a.M_tot) - 1.0) * (sp - sm) / n;
+                // g = (o0 - 1)(o+ - o-): nonzero only where o0 = 0 (not counted): -(o+ - o-)
+                acc[1] += -(d_b - u_b);
+                acc[2] += d_b + u_b;
+            }
+            acc[3] += sd;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[k][tid] = acc[k];
+    __syncthreads();
+    for (int h = kT / 2; h > 0; h >>= 1) {
+        if (tid < h) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) red[k][tid] += red[k][tid + h];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double N = red[3][0];
+        a.out[2 * c] = red[0][0];
+        a.out[2 * c + 1] = (red[2][0] - red[1][0] * red[1][0] / N) / (N - 1.0);   // np.var(..., ddof=1)
+    }
+}
+
 }  // namespace
 
 size_t mse_stats_workspace_bytes(int64_t B, int P) {
@@ -225,6 +331,19 @@ int mse_stats_launch(hipStream_t stream, const double* d_E, const double* d_est,
     const int n = (P + 1) * kQ;
     hipLaunchKernelGGL(k_mse_stats_finish, dim3((unsigned)((n + kT - 1) / kT)), dim3(kT), 0, stream, d_workspace, (int)tiles,
                        P + 1, d_out);
+    VQA_HIP(hipGetLastError());
+    return VQA_OK;
+}
+
+int irandom_stats_launch(hipStream_t stream, const double* d_expect, int n_obs, const int32_t* d_label, const double* d_y,
+                         const int64_t* d_shots, const int32_t* d_seg, const double* d_n_list, int C, int kind,
+                         int has_scale, double w, double M_tot, uint64_t seed, double* d_out) {
+    if (C <= 0) return VQA_OK;
+    IRandomArgs a;
+    a.expect = d_expect; a.n_obs = n_obs; a.label = d_label; a.y = d_y; a.shots = d_shots; a.seg = d_seg;
+    a.n_list = d_n_list; a.C = C; a.kind = kind; a.has_scale = has_scale; a.w = w; a.M_tot = M_tot; a.seed = seed;
+    a.out = d_out;
+    hipLaunchKernelGGL(k_irandom_stats, dim3(C), dim3(kT), 0, stream, a);
     VQA_HIP(hipGetLastError());
     return VQA_OK;
 }

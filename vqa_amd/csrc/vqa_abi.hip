@@ -835,6 +835,26 @@ int vqa_mse_stats_dev(int device, void* stream, const double* d_expect, const do
                             want_variances, n0, second_order, d_workspace, d_out_sums, d_out_m0, d_out_grad_data);
 }
 
+int vqa_irandom_stats_dev(int device, void* stream, const double* d_expect, int n_obs, const int32_t* d_label,
+                          const double* d_y, const int64_t* d_shots, const int32_t* d_seg, const double* d_n_list,
+                          int n_components, int kind, int has_scale, double w, double M_tot, uint64_t seed,
+                          double* d_out) {
+    if (n_components < 0) VQA_FAIL(VQA_EINVAL, "n_components must be >= 0");
+    if (n_components == 0) return VQA_OK;
+    if (kind != 0 && kind != 1) VQA_FAIL(VQA_EINVAL, "kind must be 0 (Z0 outcomes) or 1 (class successes)");
+    if (n_obs < 1) VQA_FAIL(VQA_EINVAL, "n_obs must be >= 1");
+    if (!d_expect || !d_shots || !d_seg || !d_n_list || !d_out) VQA_FAIL(VQA_EINVAL, "expect, shots, seg, n_list and out must not be NULL");
+    if (kind == 0 && !d_y) VQA_FAIL(VQA_EINVAL, "kind 0 needs the labels y");
+    if (kind == 1 && !d_label) VQA_FAIL(VQA_EINVAL, "kind 1 needs the class labels");
+    if (kind == 1 && has_scale) VQA_FAIL(VQA_EINVAL, "the classifier has no scale parameter");
+    int count = 0;
+    VQA_HIP(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) VQA_FAIL(VQA_ENODEVICE, "device %d out of range (%d visible)", device, count);
+    VQA_HIP(hipSetDevice(device));
+    return irandom_stats_launch((hipStream_t)stream, d_expect, n_obs, d_label, d_y, d_shots, d_seg, d_n_list, n_components,
+                                kind, has_scale, w, M_tot, seed, d_out);
+}
+
 int vqa_statevector(vqa_circuit* c, int device, const double* theta, const double* input_row,
                     int shift_param, double shift_val, double* out_state) {
     if (!c) VQA_FAIL(VQA_EINVAL, "circuit handle is NULL");

@@ -210,6 +210,10 @@ int mse_stats_launch(hipStream_t stream, const double* d_E, const double* d_est,
                      int want_var, double n0, int second_order, double* d_workspace, double* d_out, double* d_m0,
                      double* d_gd);
 
+int irandom_stats_launch(hipStream_t stream, const double* d_expect, int n_obs, const int32_t* d_label, const double* d_y,
+                         const int64_t* d_shots, const int32_t* d_seg, const double* d_n_list, int C, int kind,
+                         int has_scale, double w, double M_tot, uint64_t seed, double* d_out);
+
 // Working memory of a call: the per-device workspace owned by the library (grown on demand, never
 // shrunk; users on different streams are ordered by an event) or, for a call with a fixed region,
 // the next `bytes` of that region (VQA_EUNSUPPORTED when it does not hold them).

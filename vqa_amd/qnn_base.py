@@ -870,6 +870,8 @@ class myQNN_base:
         M_tot = self.num_train_data
         theta = np.asarray(params[:self.n_c_params], dtype=np.float64)
         per_shot = self.shot_draws == "per_shot"
+        if getattr(self, "device_statistics", False) and not per_shot and hasattr(self.circuit, "handle"):
+            return self._irandom_on_device(params, n_shots_list, wt_dist, theta)
         for i in range(len(params)):
             n_shots_data_list = np.random.multinomial(n_shots_list[i], wt_dist)
             sel = np.nonzero(n_shots_data_list != 0)[0].astype(np.int32)
@@ -899,6 +901,43 @@ class myQNN_base:
                 gvar_list[i] = self._direct_sample_MSEgrad_varUB_whole(y_eval, outcomes0, w=w, Scale_para=False,
                                                                        outcomes_whole_p=outcomes_p, outcomes_whole_m=outcomes_m)
         return {"grad": grad, "gvar_list": gvar_list}
+
+
+    def _irandom_on_device(self, params, n_shots_list, wt_dist, theta, kind=0):
+        """MSE_iEval_iRandom with everything behind the shot allocation on the GPU: the multinomial
+        allocations of all components are drawn here (NumPy's generator, the reference's order,
+        myQNNs_base.py:1637), the (component, sample) rows that received shots become ONE explicit
+        instance list, and a kernel draws the joint outcome counts of every row and reduces them to
+        the gradient and variance estimates (vqa_irandom_stats_dev).  Same estimators, counters and
+        shot totals as the host path; the outcome stream is the library's."""
+        from .stats import irandom_stats
+
+        C_ = len(params)
+        has_scale = kind == 0
+        rows, shots, seg = [], [], [0]
+        for i in range(C_):
+            alloc = np.random.multinomial(n_shots_list[i], wt_dist)
+            sel = np.nonzero(alloc != 0)[0]
+            rows.append(sel)
+            shots.append(alloc[sel])
+            seg.append(seg[-1] + len(sel))
+        rows = np.concatenate(rows).astype(np.int32)
+        shots = np.concatenate(shots).astype(np.int64)
+        seed = int(np.random.randint(0, 2 ** 31 - 1))
+        if kind == 0:
+            out = irandom_stats(self.circuit, theta, self._handle("train"), self._obs_list(), rows, seg, shots,
+                                np.asarray(n_shots_list, dtype=float), float(params[-1]), self.num_train_data, seed,
+                                kind=0, has_scale=True, rows_y=self.y_train[rows])
+        else:
+            out = irandom_stats(self.circuit, theta, self._handle("train"), self.class_observables(), rows, seg, shots,
+                                np.asarray(n_shots_list, dtype=float), 1.0, self.num_train_data, seed,
+                                kind=1, has_scale=False, rows_label=np.asarray(self.y_train, dtype=np.int64)[rows])
+        n_circ_rows = seg[-2] if has_scale else seg[-1]
+        n_scale_rows = seg[-1] - n_circ_rows
+        self.circuit_counter[0] += 3 * n_circ_rows + n_scale_rows
+        self.call_counter[0] += 3 * n_circ_rows + n_scale_rows
+        self.shots_counter[0] += int(3 * shots[:n_circ_rows].sum() + 2 * shots[n_circ_rows:].sum())
+        return {"grad": out[:, 0].copy(), "gvar_list": out[:, 1].copy()}
 
 
 class myQNN_regression(myQNN_base):

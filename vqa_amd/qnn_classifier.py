@@ -478,6 +478,8 @@ class myQNN_classifier(myQNN_base):
             wt_dist = np.array(option_weight) / np.sum(option_weight)
         M_tot = self.num_train_data
         theta = np.asarray(params[:self.n_c_params], dtype=np.float64)
+        if getattr(self, "device_statistics", False) and self.shot_draws != "per_shot" and hasattr(self.circuit, "handle"):
+            return self._irandom_on_device(params, n_shots_list, wt_dist, theta, kind=1)
         for i in range(len(params)):
             n_shots_data_list = np.random.multinomial(n_shots_list[i], wt_dist)
             sel = np.nonzero(n_shots_data_list != 0)[0].astype(np.int32)

@@ -39,3 +39,36 @@ def mse_stats(E, y, w, shots=None, weight=None, n_shots0=0.0, mode=EXACT, seed=0
                                    p(weight_t), float(n_shots0), int(mode), int(seed), int(bool(want_variances)), float(n0),
                                    int(bool(second_order)), p(ws), p(out), p(m0), p(gd)))
     return out.cpu().numpy(), m0, gd
+
+
+def irandom_stats(circuit, theta, inputs, obs_list, rows_sample, rows_comp_seg, rows_shots, n_list, w, M_tot, seed,
+                  kind=0, has_scale=False, rows_y=None, rows_label=None):
+    """Gradient and variance estimates of MSE_iEval_iRandom from ONE explicit instance list on the GPU
+    (thin wrapper of vqa_eval_batch_dev + vqa_irandom_stats_dev).  rows_sample[r]: training-set index
+    of row r; rows_comp_seg[i] .. [i+1]: the rows of component i (circuit parameter i; with has_scale the
+    last component is the scale parameter, whose three instances are all unshifted).  Returns
+    out [C, 2] (gradient, variance) as numpy."""
+    import torch
+
+    C_ = len(rows_comp_seg) - 1
+    R = len(rows_sample)
+    seg = np.asarray(rows_comp_seg, np.int32)
+    comp = np.repeat(np.arange(C_, dtype=np.int32), np.diff(seg))
+    n_circ = C_ - 1 if has_scale else C_
+    si = np.repeat(np.asarray(rows_sample, np.int32), 3)
+    sp = np.repeat(np.where(comp < n_circ, comp, -1).astype(np.int32), 3)
+    sp[0::3] = -1
+    sv = np.tile(np.array([0.0, 0.5 * np.pi, -0.5 * np.pi]), R)
+    sv[sp < 0] = 0.0
+    e, _ = circuit.eval_batch(theta, inputs, sample_idx=si, shift_param=sp, shift_val=sv, obs_list=obs_list, device_out=True)
+    dev = e.device
+    t = lambda a, dt: None if a is None else torch.from_numpy(np.ascontiguousarray(a, dt)).to(dev)
+    d_y, d_lab = t(rows_y, np.float64), t(rows_label, np.int32)
+    d_shots, d_seg, d_n = t(rows_shots, np.int64), t(seg, np.int32), t(n_list, np.float64)
+    out = torch.empty((C_, 2), dtype=torch.float64, device=dev)
+    p = lambda x: None if x is None else C.c_void_p(x.data_ptr())
+    st = torch.cuda.current_stream(dev).cuda_stream
+    _lib.check(_lib.lib().vqa_irandom_stats_dev(dev.index or 0, C.c_void_p(st), p(e), int(e.shape[1]), p(d_lab), p(d_y),
+                                                p(d_shots), p(d_seg), p(d_n), C_, int(kind), int(bool(has_scale)),
+                                                float(w), float(M_tot), int(seed), p(out)))
+    return out.cpu().numpy()
