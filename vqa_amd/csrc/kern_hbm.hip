@@ -158,74 +158,109 @@ constexpr int kTileWaves = VQA_TILE_WAVES;
 constexpr int kTileWaves = 2 * (kTT / 64) / 4; // waves per SIMD with two workgroups on a CU (what their LDS allows)
 #endif
 constexpr int kGateBatch = 256;               // most gates in one pass
-constexpr int kMaxMats = 48;                  // most fused 2x2s in one pass (their matrices sit in LDS)
-constexpr int kMaxOps = 96;                   // most register operations in one pass
-constexpr int kMaxSweeps = 24;                // most sweeps in one pass
-constexpr int kMaxPhaseGates = 64;            // most diagonal gates in the pass's phase-table runs
-constexpr int kMaxDiagGates = 128;            // most diagonal gates in the pass's runs of both kinds
-constexpr int kMaxShifts = 4;                 // most distinct CZ distances in a signs-only run
+constexpr int kMaxSweeps = 64;                // most sweeps in one pass
 constexpr int kTilesPerWg = VQA_TILES_PER_WG;  // most tiles one workgroup runs one after the other
-constexpr int kGateZZ = 9;                    // internal: CNOT(c,t) RZ_t(a) CNOT(c,t) = exp(i a/2 Z_c Z_t), p0 = t, p1 = c
+// internal gate kinds (beside VQA_GATE_*)
+constexpr int kGateZZ = 9;                    // CNOT(c,t) RZ_t(a) CNOT(c,t) = exp(i a/2 Z_c Z_t), p0 = t, p1 = c
+constexpr int kGateU = 10;                    // a fused run of 1-qubit gates on one qubit with a dense 2x2, g = run number
+constexpr int kGateD1A = 11;                  // the diagonal factor behind the real rotation of fused 2x2 number g
+constexpr int kGateD1B = 12;                  // the diagonal factor in front of it
 
 // one gate of a pass: positions < 32 are tile positions, 32 + q is outer qubit q, -1 unused
 struct TileGate {
-    int32_t kind, p0, p1, g;                  // g = index into the angle table
+    int32_t kind, p0, p1, g;                  // g = index into the angle table (D1A / D1B: into the plan's table of fused 2x2s)
 };
+// Normal form.  Every maximal run of 1-qubit gates on a qubit that holds a non-diagonal gate is
+// multiplied out per instance (k_mats) and written as
+//     M = diag(A0, A1) * R * diag(1, b1),   R = [[c, -s], [s, c]],  c = |M00|, s = |M10|,  |A0| = |A1| = |b1| = 1,
+// and the real rotation R is applied as three shears  a0 -= u a1;  a1 += s a0;  a0 -= u a1  with
+// u = tan(phi / 2) = s / (1 + c) <= 1 (stable for every angle in [0, pi/2]), so the dense part costs three
+// fused multiply-adds per amplitude (a complex 2x2 costs eight) and
+// the complex factors join the diagonal gates around
+// the rotation, which are applied together, once per layer of the circuit, as a phase per amplitude.
+//
 // A pass is a list of SWEEPS over the tile in LDS.  In a sweep every thread holds the
 // amplitudes that differ in the sweep's group positions, applies the sweep's register
-// operations to them in order -- fused 2x2s on a group position (the product of the
-// 1-qubit gates that follow each other there) and CNOTs whose target is a group position
-// (the control may be any qubit) -- then the sweep's run of diagonal gates, and puts them
-// back.  A diagonal run is either a phase per amplitude (two 64-entry tables for the low
-// and the high six tile positions, plus the gates that join the halves) or, when it holds
-// only Z and CZ, a sign per amplitude from a few bit masks.
-enum { OP_MAT = 0, OP_CNOT = 1 };
-enum { DG_NONE = 0, DG_PHASE = 1, DG_SIGN = 2 };
+// operations to them in order -- rotations on a group position and CNOTs whose target is a
+// group position (the control may be any qubit) -- then the sweep's diagonal run, and puts
+// them back.  A diagonal run is a phase per amplitude: the product of a 64-entry table for the
+// low six tile positions (with the outer bits, fixed for the tile, folded in), one for the high
+// six, and the few two-qubit gates that join the halves.  The tables are worked out per instance
+// beforehand (k_prep_tab) up to the gates that involve outer qubits, which depend on the tile.
+enum { OP_ROT = 0, OP_CNOT = 1 };
 struct GroupOp {
-    int32_t type, slot, a, b;                 // MAT: a = matrix number within the pass; CNOT: a = control position
+    int32_t type, slot, a, b;                 // ROT: a = fused 2x2 number within the pass, b = 1: diag(1, b1) is applied here,
+                                              // in front of the rotation (nothing earlier in the pass could take it); CNOT: a = control position
 };
 struct MatDesc {
-    int32_t begin, count;                     // gates [begin, begin + count) of the circuit's gate image, multiplied in order
+    int32_t begin, count;                     // gates [begin, begin + count) of the plan's gate image, multiplied in order
+};
+// a diagonal run: its gates inside the tile, except the two-qubit gates that join the halves
+struct RunDesc {
+    int32_t g1_begin, g1_count;               // single-qubit gates in the plan's gate image
+    int32_t g2_begin, g2_count;               // two-qubit gates in the plan's gate image
 };
 struct SweepDesc {
     int32_t gpos[4];                          // group slot -> tile position
-    int32_t tpos[kTileBits];                  // thread bit -> tile position
-    int32_t op_begin, op_count;               // register operations of the pass
-    int32_t dg_mode, dg_begin, dg_count, dg_cross;   // DG_PHASE: gates of the phase list, the first dg_cross join the halves;
-                                                     // DG_SIGN: gates of the pass
-    int32_t n_shift, shift[kMaxShifts];       // DG_SIGN: the distances |p0 - p1| of its CZs inside the tile
+    int32_t tpos[kThreadBits];                // thread bit -> tile position
+    int32_t op_begin, op_count;               // register operations (plan numbering) of a sweep with CNOTs, in order
+    int32_t rot[4];                           // a sweep without CNOTs: the rotation on each group slot (plan numbering), -1: none
+    int32_t run;                              // diagonal run (plan numbering), -1: none
+    int32_t next_run;                         // the next diagonal run of the pass behind this sweep, -1: none
+    int32_t x_begin, x_tab, x_count;          // late gates of the run (plan numbering): the first x_tab need the tile's outer
+                                              // bits and go into the phase table, the others join the halves of the tile
 };
-struct SignRun {                              // a signs-only run with this workgroup's outer bits folded in
-    int32_t zmask, neg0, m[kMaxShifts];
+// What the pass kernel reads per instance, written by the k_prep_* kernels: everything a
+// workgroup needs besides the amplitudes is the same for all its threads, so it sits in
+// global memory in the order of use and arrives through the scalar data cache.
+struct OpRec {                                // one register operation
+    double t, u;                              // rotation: tan(phi / 2), sin(phi) of the normal form
+    int32_t code;                             // bit slot: rotation on that group slot, bit 4 + slot: CNOT onto it, bit 8: diag(1, b1) first
+    int32_t ctrl;                             // CNOT: control position
+    int32_t pad[2];
+    double2 b1;
+};
+struct XRec {                                 // one late gate: the amplitude gets v1 when sel is set, else v0
+    int32_t mode;                             // sel = bit(p0) (4), bit(p0) ^ bit(p1) (5), bit(p0) & bit(p1) with v = +-1 (2)
+    int32_t p0, p1, pad;
+    double2 v0, v1;
 };
 struct TilePassArgs {
-    int n, n_ops;
+    int n;
     int tq[kTileBits];                        // tile position -> qubit (ascending)
     int oq[32];                               // outer bit number -> qubit (ascending)
     int n_outer;
-    int n_mats, n_pops, n_sweeps;             // this pass
-    int pg_begin, pg_count, dg_total;         // its diagonal gates: [pg_begin, +dg_total), the first pg_count in phase-table runs
+    int n_sweeps, first_run;                  // this pass
+    int n_ops_total, n_runs_total, n_x_total; // row lengths of the per-instance tables
     int tiles_per_wg;
-    int mat_off, n_mats_total;                // where its matrices start in an instance's row of the matrix table
+#ifdef VQA_TILE_ABLATE
+    int ablate;                               // timing experiments (libvqahip_abl.so): bit 0 no sweeps, 1 no LDS traffic in the sweeps, 2 no register operations, 3 no diagonal runs
+#endif
 };
 
 struct c2 {
     double x, y;
 };
-__device__ __forceinline__ c2 cm(c2 a, c2 b) { return { a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x }; }
-__device__ __forceinline__ c2 ca(c2 a, c2 b) { return { a.x + b.x, a.y + b.y }; }
+__host__ __device__ __forceinline__ c2 cm(c2 a, c2 b) { return { a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x }; }
+__host__ __device__ __forceinline__ c2 ca(c2 a, c2 b) { return { a.x + b.x, a.y + b.y }; }
+__device__ __forceinline__ c2 cdiv(c2 a, c2 b) {
+    const double d = 1.0 / (b.x * b.x + b.y * b.y);
+    return { (a.x * b.x + a.y * b.y) * d, (a.y * b.x - a.x * b.y) * d };
+}
+__device__ __forceinline__ c2 c2of(double2 v) { return { v.x, v.y }; }
+__device__ __forceinline__ double2 d2of(c2 v) { return make_double2(v.x, v.y); }
 
 __device__ __forceinline__ bool gate_bit(int p, int64_t base, int i) {
     return p >= 32 ? ((base >> (p - 32)) & 1) != 0 : ((i >> p) & 1) != 0;
 }
-__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // LDS slot of tile index i: the low four bits are XORed with the two nibbles above, so that
 // 16 indices that differ in one position of each residue class mod 4 land in 16 different
 // 16-byte bank groups (the sweeps choose their thread bits accordingly)
 __device__ __forceinline__ int tile_slot(int i) { return i ^ ((i >> 4) & 15) ^ ((i >> 8) & 15); }
 
-// the product of the 1-qubit gates [begin, begin + count) for every instance: mats[(ci * M + m) * 4 ..]
+// the product of the 1-qubit gates [begin, begin + count) for every instance, in normal form:
+// mats[(ci * M + m) * 4 ..] = (tan(phi / 2), sin(phi)), A0, A1, b1
 __global__ __launch_bounds__(kT) void k_mats(const TileGate* __restrict__ gates, const MatDesc* __restrict__ descs, int M,
                                              const double2* __restrict__ tab, int n_ops, int C, double2* __restrict__ mats) {
     const int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;
@@ -253,29 +288,175 @@ __global__ __launch_bounds__(kT) void k_mats(const TileGate* __restrict__ gates,
         const c2 n10 = ca(cm(g10, m00), cm(g11, m10)), n11 = ca(cm(g10, m01), cm(g11, m11));
         m00 = n00; m01 = n01; m10 = n10; m11 = n11;
     }
+    // M00 (or M01), M10 (or M11) and one more entry are reproduced as they are (to rounding), the
+    // fourth through the unitarity of M
+    const double tiny = 1e-150;
+    const double c = hypot(m00.x, m00.y), s = hypot(m10.x, m10.y);
+    c2 A0, A1, b1;
+    if (c >= s) {
+        A0 = { m00.x / c, m00.y / c };
+        if (s > tiny) {
+            A1 = { m10.x / s, m10.y / s };
+            b1 = cdiv(m11, { A1.x * c, A1.y * c });
+        } else {
+            A1 = { m11.x / c, m11.y / c };
+            b1 = { 1.0, 0.0 };
+        }
+    } else {
+        A1 = { m10.x / s, m10.y / s };
+        if (c > tiny) {
+            A0 = { m00.x / c, m00.y / c };
+            b1 = cdiv({ -m01.x, -m01.y }, { A0.x * s, A0.y * s });
+        } else {
+            A0 = { -m01.x / s, -m01.y / s };
+            b1 = { 1.0, 0.0 };
+        }
+    }
+    const double t = s / (1.0 + c), u = s;   // tan(phi / 2), sin(phi)
     double2* o = mats + i * 4;
-    o[0] = make_double2(m00.x, m00.y);
-    o[1] = make_double2(m01.x, m01.y);
-    o[2] = make_double2(m10.x, m10.y);
-    o[3] = make_double2(m11.x, m11.y);
+    o[0] = make_double2(t, u);
+    o[1] = d2of(A0);
+    o[2] = d2of(A1);
+    o[3] = d2of(b1);
 }
 
+// the factor a single-qubit diagonal gate puts on an amplitude whose bit is `bit`
+__device__ __forceinline__ c2 diag1_factor(const TileGate& tg, bool bit, const double2* __restrict__ tab_row,
+                                           const double2* __restrict__ mats_row) {
+    if (tg.kind == VQA_GATE_RZ) {
+        const double2 cs = tab_row[tg.g];
+        return { cs.x, bit ? -cs.y : cs.y };
+    }
+    if (tg.kind == VQA_GATE_Z) return { bit ? -1.0 : 1.0, 0.0 };
+    const double2* m = mats_row + (int64_t)tg.g * 4;
+    if (tg.kind == kGateD1A) return c2of(bit ? m[2] : m[1]);
+    return bit ? c2of(m[3]) : c2{ 1.0, 0.0 };
+}
+
+// the register operations of every instance: oprec[ci * NO + o]
+__global__ __launch_bounds__(kT) void k_prep_ops(const GroupOp* __restrict__ ops, const int32_t* __restrict__ op_mat0, int NO,
+                                                 int C, const double2* __restrict__ mats, int M, OpRec* __restrict__ oprec) {
+    const int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;
+    if (i >= (int64_t)C * NO) return;
+    const int ci = (int)(i / NO), o = (int)(i - (int64_t)ci * NO);
+    const GroupOp op = ops[o];
+    OpRec r;
+    r.t = r.u = 0.0;
+    r.ctrl = r.pad[0] = r.pad[1] = 0;
+    r.b1 = make_double2(1.0, 0.0);
+    if (op.type == OP_ROT) {
+        const double2* m = mats + ((int64_t)ci * M + op_mat0[o] + op.a) * 4;
+        r.t = m[0].x;
+        r.u = m[0].y;
+        r.b1 = m[3];
+        r.code = (1 << op.slot) | (op.b ? 256 : 0);
+    } else {
+        r.code = 16 << op.slot;
+        r.ctrl = op.a;
+    }
+    oprec[i] = r;
+}
+
+// the two 64-entry phase tables of every diagonal run of every instance, without the late gates:
+// pretab[(ci * NR + run) * 128 + e], e < 64: low six tile bits = e, e >= 64: high six = e - 64
+__global__ __launch_bounds__(128) void k_prep_tab(const TileGate* __restrict__ gates, const RunDesc* __restrict__ runs, int NR,
+                                                  const double2* __restrict__ tab, int n_ops, const double2* __restrict__ mats,
+                                                  int M, double2* __restrict__ pretab) {
+    const int run = blockIdx.x, ci = blockIdx.y, tid = threadIdx.x;
+    const RunDesc rd = runs[run];
+    const int half = tid >> 6, i = half ? (tid & 63) << 6 : (tid & 63);
+    const double2* tab_row = tab + (int64_t)ci * n_ops;
+    const double2* mats_row = mats + (int64_t)ci * M * 4;
+    c2 ph = { 1.0, 0.0 };
+    for (int g = rd.g1_begin; g < rd.g1_begin + rd.g1_count; ++g) {
+        const TileGate tg = gates[g];
+        if ((int)(tg.p0 >= 6) != half) continue;
+        ph = cm(ph, diag1_factor(tg, (i >> tg.p0) & 1, tab_row, mats_row));
+    }
+    bool neg = false;
+    for (int g = rd.g2_begin; g < rd.g2_begin + rd.g2_count; ++g) {
+        const TileGate tg = gates[g];
+        if ((int)(tg.p0 >= 6) != half) continue;
+        const bool b0 = (i >> tg.p0) & 1, b1 = (i >> tg.p1) & 1;
+        if (tg.kind == kGateZZ) {
+            const double2 cs = tab_row[tg.g];
+            ph = cm(ph, { cs.x, b0 != b1 ? -cs.y : cs.y });
+        } else {
+            neg ^= b0 && b1;
+        }
+    }
+    if (neg) ph = { -ph.x, -ph.y };
+    pretab[((int64_t)ci * NR + run) * 128 + tid] = d2of(ph);
+}
+
+// the late gates of every instance: xrec[ci * NX + k]
+__global__ __launch_bounds__(kT) void k_prep_x(const TileGate* __restrict__ xg, int NX, int C, const double2* __restrict__ tab,
+                                               int n_ops, XRec* __restrict__ xrec) {
+    const int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;
+    if (i >= (int64_t)C * NX) return;
+    const int ci = (int)(i / NX), k = (int)(i - (int64_t)ci * NX);
+    const TileGate tg = xg[k];
+    XRec r;
+    r.p0 = tg.p0;
+    r.p1 = tg.p1 < 0 ? tg.p0 : tg.p1;
+    r.pad = 0;
+    r.v0 = make_double2(1.0, 0.0);
+    r.v1 = make_double2(-1.0, 0.0);
+    if (tg.kind == VQA_GATE_RZ || tg.kind == kGateZZ) {
+        const double2 cs = tab[(int64_t)ci * n_ops + tg.g];
+        r.mode = tg.kind == kGateZZ ? 5 : 4;
+        r.v0 = cs;
+        r.v1 = make_double2(cs.x, -cs.y);
+    } else {
+        r.mode = tg.kind == VQA_GATE_CZ ? 2 : 4;   // Z: v = +-1 by its one bit
+    }
+    xrec[i] = r;
+}
+
+// The amplitude updates are written as inline assembly with tied operands so that they are in
+// place by construction: behind the uniform branches of the loop over the operations anything
+// else makes the register allocator keep a second copy of the state and move it back after
+// every operation.
+//   (a0, a1) <- (c a0 - s a1, s a0 + c a1) as three shears, t = tan(phi / 2), u = sin(phi), for the
+// two components of two pairs at once (the steps of a pair depend on each other)
+__device__ __forceinline__ void shear_quad(double& a0, double& a1, double& b0, double& b1, double& c0, double& c1,
+                                           double& d0, double& d1, double t, double u) {
+    asm("v_fma_f64 %0, -%8, %1, %0\n\tv_fma_f64 %2, -%8, %3, %2\n\tv_fma_f64 %4, -%8, %5, %4\n\tv_fma_f64 %6, -%8, %7, %6\n\t"
+        "v_fma_f64 %1, %9, %0, %1\n\tv_fma_f64 %3, %9, %2, %3\n\tv_fma_f64 %5, %9, %4, %5\n\tv_fma_f64 %7, %9, %6, %7\n\t"
+        "v_fma_f64 %0, -%8, %1, %0\n\tv_fma_f64 %2, -%8, %3, %2\n\tv_fma_f64 %4, -%8, %5, %4\n\tv_fma_f64 %6, -%8, %7, %6"
+        : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "+v"(c0), "+v"(c1), "+v"(d0), "+v"(d1)
+        : "s"(t), "s"(u));
+}
+//   (ax + i ay) <- (ax + i ay) (tx + i ty)
+__device__ __forceinline__ void cmul_inplace(double& ax, double& ay, double tx, double ty) {
+    double t1, t2;
+    asm("v_mul_f64 %2, %1, %5\n\tv_mul_f64 %3, %1, %4\n\tv_fma_f64 %1, %0, %5, %3\n\tv_fma_f64 %0, %0, %4, -%2"
+        : "+v"(ax), "+v"(ay), "=&v"(t1), "=&v"(t2)
+        : "v"(tx), "v"(ty));
+}
+//   (a, b) <- (b, a) where m1 = 1, m0 = 0; unchanged where m1 = 0, m0 = 1 (exact: products with 0 and 1 of finite numbers)
+__device__ __forceinline__ void cswap_inplace(double& a, double& b, double m0, double m1) {
+    double t1, t2;
+    asm("v_mul_f64 %2, %1, %5\n\tv_mul_f64 %3, %0, %5\n\tv_fma_f64 %0, %0, %4, %2\n\tv_fma_f64 %1, %1, %4, %3"
+        : "+v"(a), "+v"(b), "=&v"(t1), "=&v"(t2)
+        : "v"(m0), "v"(m1));
+}
+
+// the rotation of a fused 2x2 on group slot J (see "Normal form"); pre: diag(1, b1) first
 template <int J>
-__device__ __forceinline__ void apply_mat(double2 (&a)[kTA], const double2* m) {
-    const double2 m00 = m[0], m01 = m[1], m10 = m[2], m11 = m[3];
+__device__ __forceinline__ void apply_rot(double2 (&a)[kTA], double t, double u, bool pre, c2 b1) {
+    if (pre) {
 #pragma unroll
-    for (int r = 0; r < kTA; ++r) {
-        if (r & (1 << J)) continue;
-        const double2 a0 = a[r], a1 = a[r | (1 << J)];
-        double2 r0, r1;
-        r0.x = m00.x * a0.x - m00.y * a0.y + m01.x * a1.x - m01.y * a1.y;
-        r0.y = m00.x * a0.y + m00.y * a0.x + m01.x * a1.y + m01.y * a1.x;
-        r1.x = m10.x * a0.x - m10.y * a0.y + m11.x * a1.x - m11.y * a1.y;
-        r1.y = m10.x * a0.y + m10.y * a0.x + m11.x * a1.y + m11.y * a1.x;
-        a[r] = r0;
-        a[r | (1 << J)] = r1;
-        // two pairs at a time: all of them at once would double the live registers
-        if (kTA > 8 && (r & ((2 << J) | 1 | (J == 0 ? 2 : 0))) != 0) __builtin_amdgcn_sched_barrier(0);
+        for (int r = 0; r < kTA; ++r)
+            if (r & (1 << J)) cmul_inplace(a[r].x, a[r].y, b1.x, b1.y);
+    }
+    // the pairs of slot J, two at a time
+    constexpr int lo = (1 << J) - 1;
+#pragma unroll
+    for (int q = 0; q < kTA / 2; q += 2) {
+        const int r0 = ((q & ~lo) << 1) | (q & lo), r1 = (((q + 1) & ~lo) << 1) | ((q + 1) & lo);
+        shear_quad(a[r0].x, a[r0 | (1 << J)].x, a[r0].y, a[r0 | (1 << J)].y, a[r1].x, a[r1 | (1 << J)].x, a[r1].y,
+                   a[r1 | (1 << J)].y, t, u);
     }
 }
 
@@ -284,11 +465,10 @@ __device__ __forceinline__ void apply_cnot(double2 (&a)[kTA], int cpos, int64_t 
 #pragma unroll
     for (int r = 0; r < kTA; ++r) {
         if (r & (1 << J)) continue;
-        if (gate_bit(cpos, base, ib | off[r])) {
-            const double2 t = a[r];
-            a[r] = a[r | (1 << J)];
-            a[r | (1 << J)] = t;
-        }
+        const bool on = gate_bit(cpos, base, ib | off[r]);
+        const double m1 = on ? 1.0 : 0.0, m0 = on ? 0.0 : 1.0;
+        cswap_inplace(a[r].x, a[r | (1 << J)].x, m0, m1);
+        cswap_inplace(a[r].y, a[r | (1 << J)].y, m0, m1);
     }
 }
 
@@ -303,24 +483,35 @@ __device__ __forceinline__ uint32_t tile_base(const TilePassArgs& a, uint32_t w)
     return base;
 }
 
+// one register operation: the record has one bit per alternative, tested one after the other
+// (blocks, not a switch: each block then updates the amplitudes in place, and they stay in one
+// set of registers around the loop over the operations)
+__device__ __forceinline__ void apply_op(double2 (&v)[kTA], const OpRec& r, int64_t base, int ib, const int (&off)[kTA]) {
+    const bool pre = (r.code & 256) != 0;
+    const c2 b1 = c2of(r.b1);
+    if (r.code & 1) apply_rot<0>(v, r.t, r.u, pre, b1);
+    if (r.code & 2) apply_rot<1>(v, r.t, r.u, pre, b1);
+    if (r.code & 4) apply_rot<2>(v, r.t, r.u, pre, b1);
+    if (kGroup > 3 && (r.code & 8)) apply_rot<kGroup - 1>(v, r.t, r.u, pre, b1);
+    if (r.code & 16) apply_cnot<0>(v, r.ctrl, base, ib, off);
+    if (r.code & 32) apply_cnot<1>(v, r.ctrl, base, ib, off);
+    if (r.code & 64) apply_cnot<2>(v, r.ctrl, base, ib, off);
+    if (kGroup > 3 && (r.code & 128)) apply_cnot<kGroup - 1>(v, r.ctrl, base, ib, off);
+}
+
 // One workgroup runs the pass on `tiles_per_wg` tiles of one instance, one after the other:
 // the next tile's amplitudes are fetched from HBM while the sweeps of the current one run.
-__global__ __launch_bounds__(kTT, kTileWaves) void k_tile_pass(double2* __restrict__ st, const TileGate* __restrict__ gates,
-                                                   const GroupOp* __restrict__ ops, const SweepDesc* __restrict__ sweeps,
-                                                   const double2* __restrict__ tab, const double2* __restrict__ mats,
-                                                   TilePassArgs a) {
+__global__ __launch_bounds__(kTT, kTileWaves) void k_tile_pass(double2* __restrict__ st, const SweepDesc* __restrict__ sweeps,
+                                                   const OpRec* __restrict__ oprec, const double2* __restrict__ pretab,
+                                                   const XRec* __restrict__ xrec, TilePassArgs a) {
     extern __shared__ double2 tile[];
-    __shared__ double2 smat[kMaxMats * 4];
-    __shared__ double2 dtab[2][128];
-    __shared__ GroupOp s_ops[kMaxOps];
-    __shared__ SweepDesc s_sw[kMaxSweeps];
-    __shared__ SignRun s_sign[kMaxSweeps];
-    __shared__ TileGate s_dg[kMaxDiagGates];
-    __shared__ double2 s_dcs[kMaxPhaseGates];
+    __shared__ double2 dtab[128];
     const int tid = threadIdx.x;
     const int ci = blockIdx.y;
     double2* s = st + ((int64_t)ci << a.n);
-    tab += (int64_t)ci * a.n_ops;
+    const OpRec* __restrict__ my_ops = oprec + (int64_t)ci * a.n_ops_total;
+    const double2* __restrict__ my_tab = pretab + (int64_t)ci * a.n_runs_total * 128;
+    const XRec* __restrict__ my_x = xrec + (int64_t)ci * a.n_x_total;
     // local index l = k * kTT + tid (12 bits) -> global index; the low four bits are contiguous
     // (state indices fit 32 bits: at most 30 qubits)
     uint32_t g_tid = tid & ((1 << kTileLow) - 1);
@@ -346,49 +537,17 @@ __global__ __launch_bounds__(kTT, kTileWaves) void k_tile_pass(double2* __restri
             pv[2 * k + 1] = t2.y;
         }
     }
-    // the pass's tables, into LDS while the first amplitudes are on their way
-    for (int k = tid; k < a.n_pops; k += kTT) s_ops[k] = ops[k];
-    for (int k = tid; k < a.n_sweeps * (int)(sizeof(SweepDesc) / 4); k += kTT)
-        reinterpret_cast<int32_t*>(s_sw)[k] = reinterpret_cast<const int32_t*>(sweeps)[k];
-    for (int k = tid; k < 4 * a.n_mats; k += kTT)
-        smat[k] = mats[((int64_t)ci * a.n_mats_total + a.mat_off) * 4 + k];
-    for (int k = tid; k < a.dg_total; k += kTT) {
-        const TileGate tg = gates[a.pg_begin + k];
-        s_dg[k] = tg;
-        if (k < a.pg_count) s_dcs[k] = tab[tg.g];
-    }
+#ifdef VQA_TILE_ABLATE
+    const int abl = a.ablate;
+#else
+    constexpr int abl = 0;
+#endif
     for (int t = 0; t < (kTilesPerWg > 1 ? a.tiles_per_wg : 1); ++t) {
         const uint32_t base = tile_base(a, w0 + t);
-        lds_barrier();   // tables staged (t = 0) / the previous tile has left LDS
-        if (tid < a.n_sweeps) {
-            const SweepDesc& sd = s_sw[tid];
-            if (sd.dg_mode == DG_SIGN) {
-                // fold this tile's outer bits into the run's masks
-                SignRun sr;
-                sr.zmask = 0;
-                sr.neg0 = 0;
-#pragma unroll
-                for (int j = 0; j < kMaxShifts; ++j) sr.m[j] = 0;
-                for (int g = sd.dg_begin; g < sd.dg_begin + sd.dg_count; ++g) {
-                    const TileGate tg = s_dg[g];
-                    if (tg.kind == VQA_GATE_Z) {
-                        if (tg.p0 < 32) sr.zmask ^= 1 << tg.p0;
-                        else sr.neg0 ^= (int)((base >> (tg.p0 - 32)) & 1);
-                    } else if (tg.p0 < 32 && tg.p1 < 32) {
-                        const int lo = min(tg.p0, tg.p1), d = max(tg.p0, tg.p1) - lo;
-#pragma unroll
-                        for (int j = 0; j < kMaxShifts; ++j)
-                            if (j < sd.n_shift && sd.shift[j] == d) sr.m[j] ^= 1 << lo;
-                    } else if (tg.p0 < 32 || tg.p1 < 32) {
-                        const int pt = tg.p0 < 32 ? tg.p0 : tg.p1, po = tg.p0 < 32 ? tg.p1 : tg.p0;
-                        if ((base >> (po - 32)) & 1) sr.zmask ^= 1 << pt;
-                    } else {
-                        sr.neg0 ^= (int)((base >> (tg.p0 - 32)) & (base >> (tg.p1 - 32)) & 1);
-                    }
-                }
-                s_sign[tid] = sr;
-            }
-        }
+        // this thread's entry of the next diagonal run's tables, fetched a run ahead
+        double2 ahead = make_double2(1.0, 0.0);
+        if (a.first_run >= 0 && tid < 128) ahead = my_tab[a.first_run * 128 + tid];
+        lds_barrier();   // the previous tile has left LDS
 #pragma unroll
         for (int k = 0; k < kTA; ++k) tile[tile_slot(k * kTT + tid)] = make_double2(pv[2 * k], pv[2 * k + 1]);
         if (kTilesPerWg > 1 && t + 1 < a.tiles_per_wg) {
@@ -400,122 +559,105 @@ __global__ __launch_bounds__(kTT, kTileWaves) void k_tile_pass(double2* __restri
                 pv[2 * k + 1] = t2.y;
             }
         }
-        for (int si = 0; si < a.n_sweeps; ++si) {
-            lds_barrier();   // the previous sweep's amplitudes (or the gathered tile) are in LDS
-            const SweepDesc& sw = s_sw[si];
-            const int dg_mode = uni(sw.dg_mode), dg_begin = uni(sw.dg_begin), dg_count = uni(sw.dg_count),
-                      dg_cross = uni(sw.dg_cross);
-            double2* dt = dtab[si & 1];
-            if (dg_mode == DG_PHASE) {
+        for (int si = 0; si < ((abl & 1) ? 0 : a.n_sweeps); ++si) {
+            lds_barrier();   // the previous sweep's amplitudes (or the gathered tile) are in LDS, its phase table has been read
+            const SweepDesc sw = sweeps[si];
+            if (sw.run >= 0) {
                 if (tid < 128) {
                     // The phase of amplitude i factors into a part from its low six tile bits (and the
                     // outer bits, fixed here), a part from its high six, and the gates that join the
-                    // two halves (the first dg_cross of the run).
+                    // two halves.  The parts come from the instance's tables; the gates that involve an
+                    // outer qubit are applied here.
                     const int half = tid >> 6, i = half ? (tid & 63) << 6 : (tid & 63);
-                    c2 ph = { 1.0, 0.0 };
-                    bool neg = false;
-                    for (int g = dg_begin + dg_cross; g < dg_begin + dg_count; ++g) {
-                        const TileGate tg = s_dg[g];
-                        const bool hi = (tg.p0 < 32 && tg.p0 >= 6) || (tg.p1 >= 6 && tg.p1 < 32);
-                        if ((int)hi != half) continue;
-                        if (tg.kind == VQA_GATE_RZ) {
-                            const double2 cs = s_dcs[g];
-                            ph = cm(ph, { cs.x, gate_bit(tg.p0, base, i) ? -cs.y : cs.y });
-                        } else if (tg.kind == kGateZZ) {
-                            const double2 cs = s_dcs[g];
-                            ph = cm(ph, { cs.x, gate_bit(tg.p0, base, i) != gate_bit(tg.p1, base, i) ? -cs.y : cs.y });
-                        } else {
-                            bool f = gate_bit(tg.p0, base, i);
-                            if (tg.kind == VQA_GATE_CZ) f = f && gate_bit(tg.p1, base, i);
-                            neg ^= f;
-                        }
+                    c2 ph = c2of(ahead);
+                    if (sw.next_run >= 0) ahead = my_tab[sw.next_run * 128 + tid];
+                    for (int k = sw.x_begin; k < sw.x_begin + sw.x_tab; ++k) {
+                        const XRec x = my_x[k];
+                        const int tp = x.p0 < 32 ? x.p0 : x.p1;   // the tile position it acts on, if any
+                        if ((int)(tp < 32 && tp >= 6) != half) continue;
+                        const bool b0 = gate_bit(x.p0, base, i), b1 = gate_bit(x.p1, base, i);
+                        const bool sel = (x.mode & 2) ? (b0 && b1) : (x.mode & 1) ? (b0 != b1) : b0;
+                        ph = cm(ph, c2of(sel ? x.v1 : x.v0));
                     }
-                    if (neg) ph = { -ph.x, -ph.y };
-                    dt[tid] = make_double2(ph.x, ph.y);
+                    dtab[tid] = d2of(ph);
                 }
                 lds_barrier();
             }
             // this thread's amplitudes: thread bits on tpos, register bits on gpos
             int ib = 0;
 #pragma unroll
-            for (int b = 0; b < kThreadBits; ++b) ib |= ((tid >> b) & 1) << uni(sw.tpos[b]);
+            for (int b = 0; b < kThreadBits; ++b) ib |= ((tid >> b) & 1) << sw.tpos[b];
             int off[kTA];
-            {
-                int gp[4];
 #pragma unroll
-                for (int j = 0; j < kGroup; ++j) gp[j] = uni(sw.gpos[j]);
+            for (int r = 0; r < kTA; ++r) {
+                off[r] = 0;
 #pragma unroll
-                for (int r = 0; r < kTA; ++r) {
-                    off[r] = 0;
-#pragma unroll
-                    for (int j = 0; j < kGroup; ++j) off[r] |= ((r >> j) & 1) << gp[j];
-                }
+                for (int j = 0; j < kGroup; ++j) off[r] |= ((r >> j) & 1) << sw.gpos[j];
             }
             const int sb = tile_slot(ib);
             double2 v[kTA];
 #pragma unroll
-            for (int r = 0; r < kTA; ++r) v[r] = tile[sb ^ tile_slot(off[r])];
-            const int o_end = uni(sw.op_begin) + uni(sw.op_count);
-            for (int o = uni(sw.op_begin); o < o_end; ++o) {
-                const GroupOp op = s_ops[o];
-                const int type = uni(op.type), slot = uni(op.slot), oa = uni(op.a);
-                if (type == OP_MAT) {
-                    const double2* m = &smat[4 * oa];
-                    switch (slot) {
-                    case 0: apply_mat<0>(v, m); break;
-                    case 1: apply_mat<1>(v, m); break;
-                    case 2: apply_mat<2>(v, m); break;
-                    default: if (kGroup > 3) apply_mat<kGroup - 1>(v, m); break;
-                    }
-                } else {
-                    switch (slot) {
-                    case 0: apply_cnot<0>(v, oa, base, ib, off); break;
-                    case 1: apply_cnot<1>(v, oa, base, ib, off); break;
-                    case 2: apply_cnot<2>(v, oa, base, ib, off); break;
-                    default: if (kGroup > 3) apply_cnot<kGroup - 1>(v, oa, base, ib, off); break;
-                    }
+            for (int r = 0; r < kTA; ++r) v[r] = (abl & 2) ? make_double2(1.0 + r, tid) : tile[sb ^ tile_slot(off[r])];
+            const int o_end = (abl & 4) ? sw.op_begin : sw.op_begin + sw.op_count;
+            if (sw.op_begin < o_end) {
+                // the next record is on its way while the current operation runs
+                OpRec cur = my_ops[sw.op_begin];
+                for (int o = sw.op_begin; o < o_end; ++o) {
+                    const OpRec nxt = my_ops[min(o + 1, o_end - 1)];
+                    apply_op(v, cur, base, ib, off);
+                    cur = nxt;
                 }
             }
-            if (dg_mode == DG_PHASE) {
+            if (sw.op_count == 0 && !(abl & 4)) {
+                // at most one rotation per group slot and nothing else: they commute, and their
+                // records are fetched together
+                const OpRec r0 = my_ops[max(sw.rot[0], 0)], r1 = my_ops[max(sw.rot[1], 0)], r2 = my_ops[max(sw.rot[2], 0)],
+                            r3 = my_ops[max(sw.rot[kGroup - 1], 0)];
+                if (sw.rot[0] >= 0) apply_rot<0>(v, r0.t, r0.u, (r0.code & 256) != 0, c2of(r0.b1));
+                if (sw.rot[1] >= 0) apply_rot<1>(v, r1.t, r1.u, (r1.code & 256) != 0, c2of(r1.b1));
+                if (sw.rot[2] >= 0) apply_rot<2>(v, r2.t, r2.u, (r2.code & 256) != 0, c2of(r2.b1));
+                if (kGroup > 3 && sw.rot[kGroup - 1] >= 0)
+                    apply_rot<kGroup - 1>(v, r3.t, r3.u, (r3.code & 256) != 0, c2of(r3.b1));
+            }
+            if (sw.run >= 0 && !(abl & 8)) {
 #pragma unroll
                 for (int r = 0; r < kTA; ++r) {
                     const int i = ib | off[r];
-                    const double2 lo = dt[i & 63], hi = dt[64 + (i >> 6)];
-                    c2 ph = cm({ lo.x, lo.y }, { hi.x, hi.y });
-                    for (int g = dg_begin; g < dg_begin + dg_cross; ++g) {
-                        const TileGate tg = s_dg[g];
-                        const int p0 = uni(tg.p0), p1 = uni(tg.p1);
-                        if (uni(tg.kind) == VQA_GATE_CZ) {
-                            if ((i >> p0) & (i >> p1) & 1) ph = { -ph.x, -ph.y };
-                        } else {
-                            const double2 cs = s_dcs[g];
-                            ph = cm(ph, { cs.x, (((i >> p0) ^ (i >> p1)) & 1) ? -cs.y : cs.y });
-                        }
-                    }
-                    const c2 rr = cm({ v[r].x, v[r].y }, ph);
-                    v[r] = make_double2(rr.x, rr.y);
+                    const c2 ph = cm(c2of(dtab[i & 63]), c2of(dtab[64 + (i >> 6)]));
+                    cmul_inplace(v[r].x, v[r].y, ph.x, ph.y);
                     if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four amplitudes' table reads in flight, not all
                 }
-            } else if (dg_mode == DG_SIGN) {
-                const SignRun& sr = s_sign[si];
-                const int zmask = uni(sr.zmask), neg0 = uni(sr.neg0), n_shift = uni(sw.n_shift);
-                int sh[kMaxShifts], mk[kMaxShifts];
+                for (int k = sw.x_begin + sw.x_tab; k < sw.x_begin + sw.x_count; ++k) {
+                    const XRec x = my_x[k];
+                    // (two blocks, not an if / else: each updates the amplitudes in place)
+                    if (x.mode & 2) {
 #pragma unroll
-                for (int j = 0; j < kMaxShifts; ++j) {
-                    sh[j] = uni(sw.shift[j]);
-                    mk[j] = j < n_shift ? uni(sr.m[j]) : 0;
-                }
+                        for (int r = 0; r < kTA; ++r) {
+                            const int i = ib | off[r];
+                            const double sg = ((i >> x.p0) & (i >> x.p1) & 1) ? -1.0 : 1.0;
+                            asm("v_mul_f64 %0, %0, %2\n\tv_mul_f64 %1, %1, %2" : "+v"(v[r].x), "+v"(v[r].y) : "v"(sg));
+                        }
+                    }
+                    if (x.mode & 4) {
 #pragma unroll
-                for (int r = 0; r < kTA; ++r) {
-                    const int i = ib | off[r];
-                    int x = i & zmask;
-#pragma unroll
-                    for (int j = 0; j < kMaxShifts; ++j) x ^= i & (i >> sh[j]) & mk[j];
-                    if ((__popc(x) ^ neg0) & 1) v[r] = make_double2(-v[r].x, -v[r].y);
+                        for (int r = 0; r < kTA; ++r) {
+                            const int i = ib | off[r];
+                            const bool sel = ((i >> x.p0) ^ ((x.mode & 1) ? (i >> x.p1) : 0)) & 1;
+                            const double2 f = sel ? x.v1 : x.v0;
+                            cmul_inplace(v[r].x, v[r].y, f.x, f.y);
+                        }
+                    }
                 }
             }
+            if (abl & 2) {
+                double acc = 0.0;
 #pragma unroll
-            for (int r = 0; r < kTA; ++r) tile[sb ^ tile_slot(off[r])] = v[r];
+                for (int r = 0; r < kTA; ++r) acc += v[r].x + v[r].y;
+                if (acc == 0.123) tile[tid] = make_double2(acc, acc);
+            } else {
+#pragma unroll
+                for (int r = 0; r < kTA; ++r) tile[sb ^ tile_slot(off[r])] = v[r];
+            }
         }
         lds_barrier();
 #pragma unroll
@@ -523,32 +665,38 @@ __global__ __launch_bounds__(kTT, kTileWaves) void k_tile_pass(double2* __restri
     }
 }
 
-// Cuts the gate list into passes.  A gate can run in a pass when its target (for
-// the non-diagonal kinds) is a tile qubit and none of its qubits is held back by
-// an earlier gate that could not run; gates that share no qubit commute, so
-// later gates on other qubits may run ahead of a held-back one.  A CNOT - RZ(target) -
-// CNOT sandwich is one diagonal ZZ phase gate.  Inside a pass
-// the gates are grouped into sweeps with the same argument: a gate goes into the
-// earliest sweep at or behind the last one that touches its qubits -- a 1-qubit gate or
-// CNOT into the sweep's register operations when its target is (or can become) one of the
-// sweep's group positions and the sweep's diagonal run does not yet touch its qubits;
-// a diagonal gate into the diagonal run of the last sweep that touches its qubits.
+// Cuts the gate list into passes.  First the list is brought into the normal form's units:
+// CNOT - RZ(target) - CNOT sandwiches become one ZZ phase gate, and every maximal run of
+// 1-qubit gates on a qubit (nothing else touches the qubit in between) that holds a
+// non-diagonal gate becomes one unit U.  A unit can run in a pass when its target (for the
+// non-diagonal kinds) is a tile qubit and none of its qubits is held back by an earlier unit
+// that could not run; units that share no qubit commute, so later ones on other qubits may run
+// ahead of a held-back one.  Inside a pass the units are grouped into sweeps with the same
+// argument: a rotation or CNOT goes into the earliest sweep at or behind the last one that
+// touches its qubits in which its target is (or can become) a group position.  Diagonal gates
+// (the units' own diagonal factors among them) wait until an operation on one of their qubits
+// needs them applied; they then join the run of the sweep the previous diagonal gates went to
+// when that is late enough, so that a layer of the circuit ends up with one diagonal run.
 struct TilePlan {
     struct Pass {
         int tq[kTileBits];
-        std::vector<TileGate> gates;   // register-operation gates, then the phase-list runs, then the signs-only runs
+        std::vector<TileGate> gates;   // the fused 2x2s' gates, the CNOTs, then the diagonal runs' gates
+        std::vector<TileGate> xgates;  // the late gates
         std::vector<GroupOp> ops;
         std::vector<MatDesc> mats;     // gate ranges relative to this pass's gates
-        std::vector<SweepDesc> sweeps;
-        int pg_begin = 0, pg_count = 0, dg_total = 0;
+        std::vector<RunDesc> runs;     // likewise
+        std::vector<SweepDesc> sweeps; // operations, runs and late gates in the pass's numbering
     };
     std::vector<Pass> passes;
-    // images copied to the device: the passes' tables one after the other
-    std::vector<TileGate> all_gates;
+    // images copied to the device: the passes' tables one after the other, in the plan's numbering
+    std::vector<TileGate> all_gates, all_xgates;
     std::vector<GroupOp> all_ops;
-    std::vector<MatDesc> all_mats;     // gate ranges in all_gates
+    std::vector<int32_t> op_mat0;      // per operation: the plan's number of its pass's first fused 2x2
+    std::vector<MatDesc> all_mats;
+    std::vector<RunDesc> all_runs;
     std::vector<SweepDesc> all_sweeps;
-    std::vector<size_t> goff, ooff, moff, soff;   // where each pass starts in the images
+    std::vector<size_t> soff;          // where each pass's sweeps start
+    std::vector<int> first_run;        // each pass's first diagonal run (plan numbering), -1: none
     std::vector<int> pass_of_gate;     // gate index -> the pass that runs it
     // parameter-shift sweeps (filled by plan_sweep): the parameters that drive exactly one
     // rotation, ordered by the pass of that rotation, and the ones that drive none
@@ -557,13 +705,23 @@ struct TilePlan {
     std::vector<double> ord_coef;
 };
 
-// false when the pass needs more descriptors than the kernel holds (the caller retries with fewer gates)
-static bool group_sweeps(TilePlan::Pass& pass, const std::vector<TileGate>& in_order) {
-    struct HOp { int type, pos, ctrl; std::vector<TileGate> gates; };
+static bool diag_kind(int kind) {
+    return kind == VQA_GATE_RZ || kind == VQA_GATE_Z || kind == VQA_GATE_CZ || kind == kGateZZ || kind == kGateD1A ||
+           kind == kGateD1B;
+}
+
+// false when the pass needs more descriptors than the kernel holds (the caller retries with fewer units).
+// runs[u] = the gates of unit U number u (their p0 is filled in here).
+static bool group_sweeps(TilePlan::Pass& pass, const std::vector<TileGate>& in_order,
+                         const std::vector<std::vector<TileGate>>& runs) {
+    struct HOp { int type, pos, ctrl, mat, pre; TileGate cnot; };
     struct HSweep { std::vector<int> gpos; std::vector<HOp> ops; std::vector<TileGate> diag; };
     std::vector<HSweep> sweeps;
-    std::map<int, std::pair<int, int>> last;   // position -> (sweep, 0 = register operations | 1 = diagonal run)
-    auto last_of = [&](int p) { auto it = last.find(p); return it == last.end() ? std::make_pair(-1, 0) : it->second; };
+    std::map<int, int> last_op, last_diag;   // position -> last sweep with a register operation on it / a diagonal gate on it
+    auto lo = [&](int p) { auto it = last_op.find(p); return it == last_op.end() ? -1 : it->second; };
+    auto ld = [&](int p) { auto it = last_diag.find(p); return it == last_diag.end() ? -1 : it->second; };
+    std::vector<TileGate> pending;
+    int last_flush = -1;
     auto fits = [&](const HSweep& sw, int t) {
         if (std::find(sw.gpos.begin(), sw.gpos.end(), t) != sw.gpos.end()) return true;
         if ((int)sw.gpos.size() >= kGroup) return false;
@@ -573,52 +731,61 @@ static bool group_sweeps(TilePlan::Pass& pass, const std::vector<TileGate>& in_o
         for (int p = 0; p < kTileBits; ++p) members += (p & 3) == (t & 3);
         return same + 1 < members;
     };
-    for (const TileGate& tg : in_order) {
-        const bool diag = tg.kind == VQA_GATE_RZ || tg.kind == VQA_GATE_Z || tg.kind == VQA_GATE_CZ || tg.kind == kGateZZ;
-        std::pair<int, int> dep = last_of(tg.p0);
-        if (tg.p1 >= 0) dep = std::max(dep, last_of(tg.p1));
-        bool as_op = !diag;
-        if (diag && tg.p1 < 0 && tg.p0 < 32 && dep.first >= 0 && dep.second == 0) {
-            // RZ / Z straight behind a fused 2x2 of its qubit joins that product
-            const HSweep& sw = sweeps[dep.first];
-            for (auto it = sw.ops.rbegin(); it != sw.ops.rend(); ++it) {
-                if (it->pos == tg.p0 || it->ctrl == tg.p0) {
-                    as_op = it->type == OP_MAT && it->pos == tg.p0;
-                    break;
-                }
-            }
+    // applies the waiting diagonal gates that touch position p (p < 0: all of them)
+    auto flush = [&](int p) {
+        std::vector<TileGate> take, keep;
+        for (const TileGate& d : pending) ((p < 0 || d.p0 == p || d.p1 == p) ? take : keep).push_back(d);
+        if (take.empty()) return;
+        int f = 0;
+        for (const TileGate& d : take) {
+            f = std::max(f, lo(d.p0));
+            if (d.p1 >= 0) f = std::max(f, lo(d.p1));
         }
-        if (as_op) {
-            int s = dep.first < 0 ? 0 : dep.second == 0 ? dep.first : dep.first + 1;
-            while (s < (int)sweeps.size() && !fits(sweeps[s], tg.p0)) ++s;
-            if (s >= (int)sweeps.size()) { sweeps.emplace_back(); s = (int)sweeps.size() - 1; }
-            HSweep& sw = sweeps[s];
-            if (std::find(sw.gpos.begin(), sw.gpos.end(), tg.p0) == sw.gpos.end()) sw.gpos.push_back(tg.p0);
-            if (tg.kind == VQA_GATE_CNOT) {
-                sw.ops.push_back(HOp{ OP_CNOT, tg.p0, tg.p1, { tg } });
-                last[tg.p1] = std::max(last_of(tg.p1), std::make_pair(s, 0));
-            } else {
-                HOp* into = nullptr;
-                for (auto it = sw.ops.rbegin(); it != sw.ops.rend(); ++it) {
-                    if (it->pos == tg.p0 || it->ctrl == tg.p0) {
-                        if (it->type == OP_MAT && it->pos == tg.p0) into = &*it;
-                        break;
-                    }
-                }
-                if (into) into->gates.push_back(tg);
-                else sw.ops.push_back(HOp{ OP_MAT, tg.p0, -1, { tg } });
+        f = std::max(f, last_flush);
+        if (sweeps.empty()) sweeps.emplace_back();
+        last_flush = f;
+        for (const TileGate& d : take) {
+            sweeps[f].diag.push_back(d);
+            last_diag[d.p0] = std::max(ld(d.p0), f);
+            if (d.p1 >= 0) last_diag[d.p1] = std::max(ld(d.p1), f);
+        }
+        pending.swap(keep);
+    };
+    auto place = [&](int target, int ctrl) {
+        flush(target);
+        int s = std::max({ lo(target), ld(target) + 1, ctrl >= 0 ? lo(ctrl) : -1, 0 });
+        while (s < (int)sweeps.size() && !fits(sweeps[s], target)) ++s;
+        if (s >= (int)sweeps.size()) { sweeps.emplace_back(); s = (int)sweeps.size() - 1; }
+        HSweep& sw = sweeps[s];
+        if (std::find(sw.gpos.begin(), sw.gpos.end(), target) == sw.gpos.end()) sw.gpos.push_back(target);
+        last_op[target] = s;
+        if (ctrl >= 0) last_op[ctrl] = std::max(lo(ctrl), s);
+        return s;
+    };
+    for (const TileGate& tg : in_order) {
+        if (tg.kind == kGateU) {
+            const int p = tg.p0, mat = (int)pass.mats.size();
+            pass.mats.push_back(MatDesc{ (int)pass.gates.size(), (int)runs[tg.g].size() });
+            for (TileGate e : runs[tg.g]) {
+                e.p0 = p;
+                pass.gates.push_back(e);
             }
-            last[tg.p0] = std::max(last_of(tg.p0), std::make_pair(s, 0));
+            bool touched = lo(p) >= 0 || ld(p) >= 0;
+            for (const TileGate& d : pending) touched |= d.p0 == p || d.p1 == p;
+            if (touched) pending.push_back(TileGate{ kGateD1B, p, -1, mat });
+            const int s = place(p, -1);
+            sweeps[s].ops.push_back(HOp{ OP_ROT, p, -1, mat, touched ? 0 : 1, {} });
+            pending.push_back(TileGate{ kGateD1A, p, -1, mat });
+        } else if (tg.kind == VQA_GATE_CNOT) {
+            const int s = place(tg.p0, tg.p1);
+            sweeps[s].ops.push_back(HOp{ OP_CNOT, tg.p0, tg.p1, -1, 0, tg });
         } else {
-            int s = std::max(dep.first, 0);
-            if (sweeps.empty()) sweeps.emplace_back();
-            sweeps[s].diag.push_back(tg);
-            last[tg.p0] = std::max(last_of(tg.p0), std::make_pair(s, 1));
-            if (tg.p1 >= 0) last[tg.p1] = std::max(last_of(tg.p1), std::make_pair(s, 1));
+            pending.push_back(tg);
         }
     }
+    flush(-1);
     if ((int)sweeps.size() > kMaxSweeps) return false;
-    std::vector<TileGate> phase_list, sign_list;
+    std::vector<TileGate> run_gates, cnot_gates;
     for (HSweep& hs : sweeps) {
         SweepDesc sd;
         memset(&sd, 0, sizeof(sd));
@@ -638,68 +805,74 @@ static bool group_sweeps(TilePlan::Pass& pass, const std::vector<TileGate>& in_o
         tp.insert(tp.end(), rest.begin(), rest.end());
         for (int j = 0; j < kGroup; ++j) sd.gpos[j] = hs.gpos[j];
         for (int b = 0; b < kThreadBits; ++b) sd.tpos[b] = tp[b];
+        bool has_cnot = false;
+        for (const HOp& op : hs.ops) has_cnot |= op.type == OP_CNOT;
         sd.op_begin = (int)pass.ops.size();
+        for (int j = 0; j < 4; ++j) sd.rot[j] = -1;
         for (const HOp& op : hs.ops) {
             const int slot = (int)(std::find(hs.gpos.begin(), hs.gpos.end(), op.pos) - hs.gpos.begin());
-            if (op.type == OP_MAT) {
-                pass.ops.push_back(GroupOp{ OP_MAT, slot, (int)pass.mats.size(), 0 });
-                pass.mats.push_back(MatDesc{ (int)pass.gates.size(), (int)op.gates.size() });
-                pass.gates.insert(pass.gates.end(), op.gates.begin(), op.gates.end());
+            if (op.type == OP_ROT) {
+                if (!has_cnot) sd.rot[slot] = (int)pass.ops.size();   // one per slot: a second one waits for the first one's diagonal factor
+                pass.ops.push_back(GroupOp{ OP_ROT, slot, op.mat, op.pre });
             } else {
                 pass.ops.push_back(GroupOp{ OP_CNOT, slot, op.ctrl, 0 });
-                pass.gates.push_back(op.gates[0]);   // kept for the gate -> pass map
+                cnot_gates.push_back(op.cnot);
             }
         }
-        sd.op_count = (int)pass.ops.size() - sd.op_begin;
-        sd.dg_count = (int)hs.diag.size();
+        sd.op_count = has_cnot ? (int)pass.ops.size() - sd.op_begin : 0;
+        sd.run = sd.next_run = -1;
         if (!hs.diag.empty()) {
-            bool signs = true;
-            std::vector<int> shifts;
-            for (const TileGate& t : hs.diag) {
-                signs &= t.kind == VQA_GATE_Z || t.kind == VQA_GATE_CZ;
-                if (t.kind == VQA_GATE_CZ && t.p0 < 32 && t.p1 < 32) {
-                    const int d = std::abs(t.p0 - t.p1);
-                    if (std::find(shifts.begin(), shifts.end(), d) == shifts.end()) shifts.push_back(d);
-                }
+            // the gates inside the tile that stay within a half go into the instance's tables;
+            // late gates: first those with an outer qubit, then those that join the halves
+            auto high = [](int p) { return p >= 6; };
+            std::vector<TileGate> one, two, x_tab, x_cross;
+            for (const TileGate& d : hs.diag) {
+                const bool o0 = d.p0 >= 32, o1 = d.p1 >= 32;
+                if (o0 || o1) x_tab.push_back(d);
+                else if (d.p1 < 0) one.push_back(d);
+                else if (high(d.p0) != high(d.p1)) x_cross.push_back(d);
+                else two.push_back(d);
             }
-            if (signs && (int)shifts.size() <= kMaxShifts) {
-                sd.dg_mode = DG_SIGN;
-                sd.n_shift = (int)shifts.size();
-                for (size_t j = 0; j < shifts.size(); ++j) sd.shift[j] = shifts[j];
-                sd.dg_begin = (int)sign_list.size();            // moved behind the phase list below
-                sign_list.insert(sign_list.end(), hs.diag.begin(), hs.diag.end());
-            } else {
-                // gates between the low six and the high six tile bits go first
-                auto cross = [](const TileGate& t) {
-                    return (t.kind == VQA_GATE_CZ || t.kind == kGateZZ) && t.p0 < 32 && t.p1 < 32 && (t.p0 < 6) != (t.p1 < 6);
-                };
-                std::stable_partition(hs.diag.begin(), hs.diag.end(), cross);
-                sd.dg_mode = DG_PHASE;
-                sd.dg_cross = (int)std::count_if(hs.diag.begin(), hs.diag.end(), cross);
-                sd.dg_begin = (int)phase_list.size();           // index into the phase list
-                phase_list.insert(phase_list.end(), hs.diag.begin(), hs.diag.end());
-            }
+            sd.run = (int)pass.runs.size();
+            RunDesc rd;
+            rd.g1_begin = (int)run_gates.size();
+            rd.g1_count = (int)one.size();
+            run_gates.insert(run_gates.end(), one.begin(), one.end());
+            rd.g2_begin = (int)run_gates.size();
+            rd.g2_count = (int)two.size();
+            run_gates.insert(run_gates.end(), two.begin(), two.end());
+            pass.runs.push_back(rd);
+            sd.x_begin = (int)pass.xgates.size();
+            sd.x_tab = (int)x_tab.size();
+            pass.xgates.insert(pass.xgates.end(), x_tab.begin(), x_tab.end());
+            pass.xgates.insert(pass.xgates.end(), x_cross.begin(), x_cross.end());
+            sd.x_count = (int)pass.xgates.size() - sd.x_begin;
         }
         pass.sweeps.push_back(sd);
     }
-    pass.pg_begin = (int)pass.gates.size();
-    pass.pg_count = (int)phase_list.size();
-    pass.gates.insert(pass.gates.end(), phase_list.begin(), phase_list.end());
-    pass.gates.insert(pass.gates.end(), sign_list.begin(), sign_list.end());
-    pass.dg_total = pass.pg_count + (int)sign_list.size();
-    for (SweepDesc& sd : pass.sweeps)
-        if (sd.dg_mode == DG_SIGN) sd.dg_begin += pass.pg_count;   // both kinds index the pass's diagonal list
-    return (int)pass.mats.size() <= kMaxMats && (int)pass.ops.size() <= kMaxOps && pass.pg_count <= kMaxPhaseGates &&
-           pass.dg_total <= kMaxDiagGates;
+    for (int si = (int)pass.sweeps.size() - 1, nxt = -1; si >= 0; --si) {
+        pass.sweeps[si].next_run = nxt;
+        if (pass.sweeps[si].run >= 0) nxt = pass.sweeps[si].run;
+    }
+    pass.gates.insert(pass.gates.end(), cnot_gates.begin(), cnot_gates.end());
+    const int run_base = (int)pass.gates.size();
+    for (RunDesc& rd : pass.runs) {
+        rd.g1_begin += run_base;
+        rd.g2_begin += run_base;
+    }
+    pass.gates.insert(pass.gates.end(), run_gates.begin(), run_gates.end());
+    return true;
 }
 
 // gate_dead (may be null): gates to leave out (outside the light cone of what a call measures)
 static TilePlan plan_tiles(int n, const std::vector<vqa_op>& ops, const std::vector<uint8_t>* gate_dead = nullptr) {
     TilePlan plan;
     auto is_dead = [&](size_t g) { return gate_dead && (*gate_dead)[g]; };
-    // the gate list with CNOT(c,t) RZ_t CNOT(c,t) sandwiches as ZZ phase gates
+    // the gate list in units: ZZ phase gates for the sandwiches, runs of 1-qubit gates per qubit
     struct PG { int kind, q0, q1, g; };
     std::vector<PG> pg;
+    std::vector<std::vector<TileGate>> runs;   // the 1-qubit gates of a run, in order
+    std::vector<int> open(n, -1);              // the run a qubit's next 1-qubit gate joins (index into pg), -1: none
     for (size_t i = 0; i < ops.size(); ++i) {
         const vqa_op& op = ops[i];
         if (is_dead(i)) continue;
@@ -707,21 +880,44 @@ static TilePlan plan_tiles(int n, const std::vector<vqa_op>& ops, const std::vec
             ops[i + 2].kind == VQA_GATE_CNOT && ops[i + 2].q0 == op.q0 && ops[i + 2].q1 == op.q1 &&
             !is_dead(i + 1) && !is_dead(i + 2)) {
             pg.push_back(PG{ kGateZZ, op.q0, op.q1, (int)i + 1 });
+            open[op.q0] = open[op.q1] = -1;
             i += 2;
-        } else {
+        } else if (op.kind == VQA_GATE_CNOT || op.kind == VQA_GATE_CZ) {
             pg.push_back(PG{ op.kind, op.q0, op.q1, (int)i });
+            open[op.q0] = open[op.q1] = -1;
+        } else {
+            if (open[op.q0] < 0) {
+                open[op.q0] = (int)pg.size();
+                pg.push_back(PG{ kGateU, op.q0, -1, (int)runs.size() });
+                runs.emplace_back();
+            }
+            runs[pg[open[op.q0]].g].push_back(TileGate{ op.kind, -1, -1, (int)i });
         }
+    }
+    // runs of diagonal gates only stay single diagonal gates
+    {
+        std::vector<PG> out;
+        for (const PG& u : pg) {
+            bool dense = false;
+            if (u.kind == kGateU)
+                for (const TileGate& e : runs[u.g]) dense |= !(e.kind == VQA_GATE_RZ || e.kind == VQA_GATE_Z);
+            if (u.kind != kGateU || dense) {
+                out.push_back(u);
+            } else {
+                for (const TileGate& e : runs[u.g]) out.push_back(PG{ e.kind, u.q0, -1, e.g });
+            }
+        }
+        pg.swap(out);
     }
     std::vector<int> todo(pg.size());
     for (size_t i = 0; i < pg.size(); ++i) todo[i] = (int)i;
-    auto diagonal = [](int kind) { return kind == VQA_GATE_RZ || kind == VQA_GATE_Z || kind == VQA_GATE_CZ || kind == kGateZZ; };
     while (!todo.empty()) {
-        // tile: the low qubits plus the first eight others that pending gates need as targets
+        // tile: the low qubits plus the first eight others that pending units need as targets
         std::vector<int> tile;
         for (int q = 0; q < kTileLow; ++q) tile.push_back(q);
         for (int gi : todo) {
             const PG& op = pg[gi];
-            if (diagonal(op.kind) || op.q0 < kTileLow) continue;
+            if (diag_kind(op.kind) || op.q0 < kTileLow) continue;
             if (std::find(tile.begin(), tile.end(), op.q0) == tile.end()) tile.push_back(op.q0);
             if ((int)tile.size() == kTileBits) break;
         }
@@ -740,7 +936,7 @@ static TilePlan plan_tiles(int n, const std::vector<vqa_op>& ops, const std::vec
             for (int gi : todo) {
                 const PG& op = pg[gi];
                 const uint64_t qs = ((uint64_t)1 << op.q0) | (op.q1 >= 0 ? (uint64_t)1 << op.q1 : 0);
-                const bool ok = !(held & qs) && (diagonal(op.kind) || pos_of[op.q0] < 32) &&
+                const bool ok = !(held & qs) && (diag_kind(op.kind) || pos_of[op.q0] < 32) &&
                                 (int)taken.size() < cap;
                 if (!ok) {
                     held |= qs;
@@ -749,7 +945,7 @@ static TilePlan plan_tiles(int n, const std::vector<vqa_op>& ops, const std::vec
                 }
                 taken.push_back(TileGate{ op.kind, pos_of[op.q0], op.q1 >= 0 ? pos_of[op.q1] : -1, op.g });
             }
-            if (!group_sweeps(pass, taken) && cap > 1) continue;
+            if (!group_sweeps(pass, taken, runs) && cap > 1) continue;
             todo.swap(rest);
             plan.passes.push_back(std::move(pass));
             break;
@@ -758,15 +954,37 @@ static TilePlan plan_tiles(int n, const std::vector<vqa_op>& ops, const std::vec
     plan.pass_of_gate.assign(ops.size(), -1);
     for (size_t k = 0; k < plan.passes.size(); ++k) {
         const auto& p = plan.passes[k];
-        plan.goff.push_back(plan.all_gates.size());
-        plan.ooff.push_back(plan.all_ops.size());
-        plan.moff.push_back(plan.all_mats.size());
         plan.soff.push_back(plan.all_sweeps.size());
-        for (const MatDesc& md : p.mats) plan.all_mats.push_back(MatDesc{ md.begin + (int)plan.all_gates.size(), md.count });
-        plan.all_gates.insert(plan.all_gates.end(), p.gates.begin(), p.gates.end());
-        plan.all_ops.insert(plan.all_ops.end(), p.ops.begin(), p.ops.end());
-        plan.all_sweeps.insert(plan.all_sweeps.end(), p.sweeps.begin(), p.sweeps.end());
-        for (const TileGate& tg : p.gates) plan.pass_of_gate[tg.g] = (int)k;
+        const int gbase = (int)plan.all_gates.size(), mbase = (int)plan.all_mats.size(), obase = (int)plan.all_ops.size(),
+                  rbase = (int)plan.all_runs.size(), xbase = (int)plan.all_xgates.size();
+        for (const MatDesc& md : p.mats) plan.all_mats.push_back(MatDesc{ md.begin + gbase, md.count });
+        for (const RunDesc& rd : p.runs)
+            plan.all_runs.push_back(RunDesc{ rd.g1_begin + gbase, rd.g1_count, rd.g2_begin + gbase, rd.g2_count });
+        for (TileGate tg : p.gates) {
+            if (tg.kind == kGateD1A || tg.kind == kGateD1B) tg.g += mbase;   // the plan's numbering of the fused 2x2s
+            else plan.pass_of_gate[tg.g] = (int)k;
+            plan.all_gates.push_back(tg);
+        }
+        for (const TileGate& tg : p.xgates) {
+            plan.pass_of_gate[tg.g] = (int)k;
+            plan.all_xgates.push_back(tg);
+        }
+        for (const GroupOp& op : p.ops) {
+            plan.all_ops.push_back(op);
+            plan.op_mat0.push_back(mbase);
+        }
+        int first = -1;
+        for (SweepDesc sd : p.sweeps) {
+            sd.op_begin += obase;
+            for (int j = 0; j < 4; ++j)
+                if (sd.rot[j] >= 0) sd.rot[j] += obase;
+            if (sd.run >= 0) sd.run += rbase;
+            if (sd.next_run >= 0) sd.next_run += rbase;
+            sd.x_begin += xbase;
+            if (first < 0 && sd.run >= 0) first = sd.run;
+            plan.all_sweeps.push_back(sd);
+        }
+        plan.first_run.push_back(first);
     }
     return plan;
 }
@@ -1134,7 +1352,7 @@ const TilePlan& plan_of(const EvalCall& call) {
             for (size_t k = 0; k < plan->passes.size(); ++k) {
                 const auto& p = plan->passes[k];
                 size_t nd = 0;
-                for (const auto& sd : p.sweeps) nd += sd.dg_count > 0;
+                for (const auto& sd : p.sweeps) nd += sd.run >= 0;
                 fprintf(stderr, "[vqa]   pass %2zu: %3zu gates, %2zu sweeps (%zu with a diagonal run), %2zu fused 2x2, %3zu register ops\n",
                         k, p.gates.size(), p.sweeps.size(), nd, p.mats.size(), p.ops.size());
             }
@@ -1163,7 +1381,6 @@ const TilePlan& cone_plan_of(const EvalCall& call) {
 
 // The plan of a layer of Hadamards on the qubits of `mask`: it turns X factors of Pauli
 // strings into Z factors, so that many X-type terms are measured in one pass over the state.
-constexpr int kHGates = 32;
 const TilePlan& hplan_of(const EvalCall& call, uint64_t mask) {
     std::lock_guard<std::mutex> lk(call.c->mu);
     auto it = call.c->hbm_hplans.find(mask);
@@ -1189,84 +1406,115 @@ uint64_t hlayer_mask(const EvalCall& call) {
     return count >= 3 ? mask : 0;
 }
 
-// device images of a plan: gates | ops | mats | sweeps, each sized for g gates
+// device images of a plan
 struct PlanImage {
     TileGate* gates;
+    TileGate* xgates;
     GroupOp* ops;
+    int32_t* op_mat0;
     MatDesc* mats;
+    RunDesc* runs;
     SweepDesc* sweeps;
 };
 static size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
+template <class T>
+static size_t vec_bytes(const std::vector<T>& v) { return pad256(std::max<size_t>(v.size(), 1) * sizeof(T)); }
 
-size_t gate_buf_bytes(size_t g) {
-    g = std::max<size_t>(g, 1);
-    return pad256(g * sizeof(TileGate)) + pad256(g * sizeof(GroupOp)) + pad256(g * sizeof(MatDesc)) +
-           pad256(g * sizeof(SweepDesc));
+size_t plan_image_bytes(const TilePlan& p) {
+    return vec_bytes(p.all_gates) + vec_bytes(p.all_xgates) + vec_bytes(p.all_ops) + vec_bytes(p.op_mat0) +
+           vec_bytes(p.all_mats) + vec_bytes(p.all_runs) + vec_bytes(p.all_sweeps);
 }
 
-PlanImage plan_image(size_t g, void* gate_buf) {
-    g = std::max<size_t>(g, 1);
-    char* w = (char*)gate_buf;
+PlanImage plan_image(const TilePlan& p, void* buf) {
+    char* w = (char*)buf;
     PlanImage im;
-    im.gates = (TileGate*)w;   w += pad256(g * sizeof(TileGate));
-    im.ops = (GroupOp*)w;      w += pad256(g * sizeof(GroupOp));
-    im.mats = (MatDesc*)w;     w += pad256(g * sizeof(MatDesc));
+    im.gates = (TileGate*)w;    w += vec_bytes(p.all_gates);
+    im.xgates = (TileGate*)w;   w += vec_bytes(p.all_xgates);
+    im.ops = (GroupOp*)w;       w += vec_bytes(p.all_ops);
+    im.op_mat0 = (int32_t*)w;   w += vec_bytes(p.op_mat0);
+    im.mats = (MatDesc*)w;      w += vec_bytes(p.all_mats);
+    im.runs = (RunDesc*)w;      w += vec_bytes(p.all_runs);
     im.sweeps = (SweepDesc*)w;
     return im;
 }
 
-// A plan with its device images and the fused-2x2 table of the instances it runs on.
+// A plan with its device images and the per-instance tables of the instances it runs on.
 struct PlanDev {
     const TilePlan* plan = nullptr;
-    size_t g = 0;            // gates the images are sized for
-    void* buf = nullptr;     // gate_buf_bytes(g)
-    double2* mats = nullptr; // [instances][all_mats][4]
-    size_t m4() const { return std::max<size_t>(plan->all_mats.size(), 1) * 4; }   // double2 per instance
-    size_t mats_bytes(int64_t C) const { return pad256((size_t)C * m4() * sizeof(double2)); }
+    void* buf = nullptr;       // plan_image_bytes(*plan)
+    char* inst = nullptr;      // inst_bytes(instances): mats | oprec | pretab | xrec, each [instances][row]
+    int64_t cap = 0;           // instances the tables are carved for
+    size_t n_mats() const { return std::max<size_t>(plan->all_mats.size(), 1); }
+    size_t n_ops() const { return std::max<size_t>(plan->all_ops.size(), 1); }
+    size_t n_runs() const { return std::max<size_t>(plan->all_runs.size(), 1); }
+    size_t n_x() const { return std::max<size_t>(plan->all_xgates.size(), 1); }
+    size_t image_bytes() const { return plan_image_bytes(*plan); }
+    size_t mats_bytes(int64_t C) const { return pad256((size_t)C * n_mats() * 4 * sizeof(double2)); }
+    size_t ops_bytes(int64_t C) const { return pad256((size_t)C * n_ops() * sizeof(OpRec)); }
+    size_t tab_bytes(int64_t C) const { return pad256((size_t)C * n_runs() * 128 * sizeof(double2)); }
+    size_t x_bytes(int64_t C) const { return pad256((size_t)C * n_x() * sizeof(XRec)); }
+    size_t inst_bytes(int64_t C) const { return mats_bytes(C) + ops_bytes(C) + tab_bytes(C) + x_bytes(C); }
+    void carve(char* p, int64_t C) { inst = p; cap = C; }
+    double2* mats(int64_t slot) const { return (double2*)inst + slot * n_mats() * 4; }
+    OpRec* oprec(int64_t slot) const { return (OpRec*)(inst + mats_bytes(cap)) + slot * n_ops(); }
+    double2* pretab(int64_t slot) const { return (double2*)(inst + mats_bytes(cap) + ops_bytes(cap)) + slot * n_runs() * 128; }
+    XRec* xrec(int64_t slot) const { return (XRec*)(inst + mats_bytes(cap) + ops_bytes(cap) + tab_bytes(cap)) + slot * n_x(); }
 };
 
 // copies the plan's tables (a plan lives as long as its circuit, so the asynchronous
 // copies may read its host images after this returns)
 int upload_plan(const EvalCall& call, const PlanDev& pd) {
     const TilePlan& plan = *pd.plan;
-    const PlanImage im = plan_image(pd.g, pd.buf);
-    if (!plan.all_gates.empty())
-        VQA_HIP(hipMemcpyAsync(im.gates, plan.all_gates.data(), plan.all_gates.size() * sizeof(TileGate),
-                               hipMemcpyHostToDevice, call.stream));
-    if (!plan.all_ops.empty())
-        VQA_HIP(hipMemcpyAsync(im.ops, plan.all_ops.data(), plan.all_ops.size() * sizeof(GroupOp),
-                               hipMemcpyHostToDevice, call.stream));
-    if (!plan.all_mats.empty())
-        VQA_HIP(hipMemcpyAsync(im.mats, plan.all_mats.data(), plan.all_mats.size() * sizeof(MatDesc),
-                               hipMemcpyHostToDevice, call.stream));
-    if (!plan.all_sweeps.empty())
-        VQA_HIP(hipMemcpyAsync(im.sweeps, plan.all_sweeps.data(), plan.all_sweeps.size() * sizeof(SweepDesc),
-                               hipMemcpyHostToDevice, call.stream));
+    const PlanImage im = plan_image(plan, pd.buf);
+    auto up = [&](void* dst, const void* src, size_t bytes) {
+        return bytes ? hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, call.stream) : hipSuccess;
+    };
+    VQA_HIP(up(im.gates, plan.all_gates.data(), plan.all_gates.size() * sizeof(TileGate)));
+    VQA_HIP(up(im.xgates, plan.all_xgates.data(), plan.all_xgates.size() * sizeof(TileGate)));
+    VQA_HIP(up(im.ops, plan.all_ops.data(), plan.all_ops.size() * sizeof(GroupOp)));
+    VQA_HIP(up(im.op_mat0, plan.op_mat0.data(), plan.op_mat0.size() * sizeof(int32_t)));
+    VQA_HIP(up(im.mats, plan.all_mats.data(), plan.all_mats.size() * sizeof(MatDesc)));
+    VQA_HIP(up(im.runs, plan.all_runs.data(), plan.all_runs.size() * sizeof(RunDesc)));
+    VQA_HIP(up(im.sweeps, plan.all_sweeps.data(), plan.all_sweeps.size() * sizeof(SweepDesc)));
     VQA_HIP(hipFuncSetAttribute((const void*)k_tile_pass, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 kTileAmps * (int)sizeof(double2)));
     return VQA_OK;
 }
 
-// the fused 2x2s of C instances (table rows slot0 ..) from their angle tables (tab_stride entries each)
+// the per-instance tables of C instances (table rows slot0 ..) from their angle tables (tab_stride entries each)
 void launch_mats(const EvalCall& call, const PlanDev& pd, const double2* tab, int tab_stride, int slot0, int C) {
-    const int M = (int)pd.plan->all_mats.size();
-    if (M == 0 || C <= 0) return;
-    const PlanImage im = plan_image(pd.g, pd.buf);
-    const int64_t tot = (int64_t)C * M;
-    hipLaunchKernelGGL(k_mats, dim3((unsigned)((tot + kT - 1) / kT)), dim3(kT), 0, call.stream, im.gates, im.mats, M, tab,
-                       tab_stride, C, pd.mats + (size_t)slot0 * pd.m4());
+    const TilePlan& plan = *pd.plan;
+    const int M = (int)plan.all_mats.size(), NO = (int)plan.all_ops.size(), NR = (int)plan.all_runs.size(),
+              NX = (int)plan.all_xgates.size();
+    if (C <= 0) return;
+    const PlanImage im = plan_image(plan, pd.buf);
+    auto grid = [](int64_t tot) { return dim3((unsigned)((tot + kT - 1) / kT)); };
+    if (M > 0)
+        hipLaunchKernelGGL(k_mats, grid((int64_t)C * M), dim3(kT), 0, call.stream, im.gates, im.mats, M, tab, tab_stride, C,
+                           pd.mats(slot0));
+    if (NO > 0)
+        hipLaunchKernelGGL(k_prep_ops, grid((int64_t)C * NO), dim3(kT), 0, call.stream, im.ops, im.op_mat0, NO, C,
+                           pd.mats(slot0), (int)pd.n_mats(), pd.oprec(slot0));
+    if (NR > 0)
+        hipLaunchKernelGGL(k_prep_tab, dim3(NR, C), dim3(128), 0, call.stream, im.gates, im.runs, NR, tab, tab_stride,
+                           pd.mats(slot0), (int)pd.n_mats(), pd.pretab(slot0));
+    if (NX > 0)
+        hipLaunchKernelGGL(k_prep_x, grid((int64_t)C * NX), dim3(kT), 0, call.stream, im.xgates, NX, C, tab, tab_stride,
+                           pd.xrec(slot0));
 }
 
-// pass k of the plan on C states side by side (st; their angle tables at tab, table rows slot0 .. of the fused 2x2s)
-void launch_pass(const EvalCall& call, const PlanDev& pd, size_t k, double2* st, const double2* tab, int tab_stride,
-                 int slot0, int C) {
+thread_local int64_t t_state_passes = 0;   // states x passes launched by this thread (VQA_PLAN_DEBUG report)
+
+// pass k of the plan on C states side by side (st; table rows slot0 .. of the per-instance tables)
+void launch_pass(const EvalCall& call, const PlanDev& pd, size_t k, double2* st, int slot0, int C) {
     const TilePlan& plan = *pd.plan;
     const auto& p = plan.passes[k];
-    if (p.gates.empty() || C <= 0) return;
+    if (p.sweeps.empty() || C <= 0) return;
+    t_state_passes += C;
     const int n = call.c->n_qubits;
-    const PlanImage im = plan_image(pd.g, pd.buf);
+    const PlanImage im = plan_image(plan, pd.buf);
     TilePassArgs a;
-    a.n = n; a.n_ops = tab_stride;
+    a.n = n;
     a.n_outer = 0;
     for (int q = 0; q < n; ++q) {
         bool in_tile = false;
@@ -1274,28 +1522,26 @@ void launch_pass(const EvalCall& call, const PlanDev& pd, size_t k, double2* st,
         if (!in_tile) a.oq[a.n_outer++] = q;
     }
     for (int t = 0; t < kTileBits; ++t) a.tq[t] = p.tq[t];
-    a.n_mats = (int)p.mats.size();
-    a.n_pops = (int)p.ops.size();
     a.n_sweeps = (int)p.sweeps.size();
-    a.pg_begin = p.pg_begin;
-    a.pg_count = p.pg_count;
-    a.dg_total = p.dg_total;
-    a.mat_off = (int)plan.moff[k];
-    a.n_mats_total = (int)plan.all_mats.size();
+    a.first_run = plan.first_run[k];
+    a.n_ops_total = (int)pd.n_ops();
+    a.n_runs_total = (int)pd.n_runs();
+    a.n_x_total = (int)pd.n_x();
     const int64_t D = (int64_t)1 << n;
     // enough workgroups to fill the GPU a few times over, else several tiles per workgroup
     const int64_t n_tiles = D >> kTileBits;
     int tpw = 1;
     while (tpw < kTilesPerWg && n_tiles % (2 * tpw) == 0 && (n_tiles / (2 * tpw)) * C >= 2048) tpw *= 2;
     a.tiles_per_wg = tpw;
+#ifdef VQA_TILE_ABLATE
+    a.ablate = getenv("VQA_TILE_ABLATE") ? atoi(getenv("VQA_TILE_ABLATE")) : 0;
+#endif
     hipLaunchKernelGGL(k_tile_pass, dim3((unsigned)(n_tiles / tpw), C), dim3(kTT), kTileAmps * sizeof(double2),
-                       call.stream, st, im.gates + plan.goff[k], im.ops + plan.ooff[k], im.sweeps + plan.soff[k], tab,
-                       pd.mats + (size_t)slot0 * pd.m4(), a);
+                       call.stream, st, im.sweeps + plan.soff[k], pd.oprec(slot0), pd.pretab(slot0), pd.xrec(slot0), a);
 }
 
-void launch_all_passes(const EvalCall& call, const PlanDev& pd, double2* st, const double2* tab, int tab_stride,
-                       int slot0, int C) {
-    for (size_t k = 0; k < pd.plan->passes.size(); ++k) launch_pass(call, pd, k, st, tab, tab_stride, slot0, C);
+void launch_all_passes(const EvalCall& call, const PlanDev& pd, double2* st, int slot0, int C) {
+    for (size_t k = 0; k < pd.plan->passes.size(); ++k) launch_pass(call, pd, k, st, slot0, C);
 }
 
 // |0..0>, the angle table and every gate for the h.C instances of a chunk; pd.plan == nullptr: one sweep per gate
@@ -1311,7 +1557,7 @@ int launch_gates(const EvalCall& call, const HbmCommon& h, double2* st, double2*
                            h, tab);
     if (pd.plan) {
         launch_mats(call, pd, tab, h.n_ops, 0, C);
-        launch_all_passes(call, pd, st, tab, h.n_ops, 0, C);
+        launch_all_passes(call, pd, st, 0, C);
         VQA_HIP(hipGetLastError());
         return VQA_OK;
     }
@@ -1467,7 +1713,7 @@ int measure_states(const EvalCall& call, double2* st, int C, int64_t e0, int nb,
             hs = hl.alt;
         }
         launch_mats(call, hl.pd, nullptr, 0, 0, C);
-        launch_all_passes(call, hl.pd, hs, nullptr, 0, 0, C);
+        launch_all_passes(call, hl.pd, hs, 0, C);
         zb.nz = 0;
         for (int o = 0; o < n_obs; ++o) {
             for (int t = call.obs.off[o]; t < call.obs.off[o + 1]; ++t) {
@@ -1524,21 +1770,17 @@ int hbm_engine_run(const EvalCall& call) {
     HLayer hl;
     if (tiled(call)) {
         pd.plan = call.cone ? &cone_plan_of(call) : &plan_of(call);
-        pd.g = (size_t)call.c->n_ops;
         hl.mask = hlayer_mask(call);
-        if (hl.mask) {
-            hl.pd.plan = &hplan_of(call, hl.mask);
-            hl.pd.g = kHGates;
-        }
+        if (hl.mask) hl.pd.plan = &hplan_of(call, hl.mask);
     }
     Carver cv;
     const size_t o_st = cv.add((size_t)Cmax * D * sizeof(double2));
     const size_t o_tab = cv.add((size_t)Cmax * std::max(call.c->n_ops, 1) * sizeof(double2));
     const size_t o_part = cv.add((size_t)Cmax * nb * kZBatch * sizeof(double));
-    const size_t o_gate = cv.add(pd.plan ? gate_buf_bytes(pd.g) : 0);
-    const size_t o_mats = cv.add(pd.plan ? pd.mats_bytes(Cmax) : 0);
-    const size_t o_hgate = cv.add(hl.pd.plan ? gate_buf_bytes(hl.pd.g) : 0);
-    const size_t o_hmats = cv.add(hl.pd.plan ? hl.pd.mats_bytes(Cmax) : 0);
+    const size_t o_gate = cv.add(pd.plan ? pd.image_bytes() : 0);
+    const size_t o_inst = cv.add(pd.plan ? pd.inst_bytes(Cmax) : 0);
+    const size_t o_hgate = cv.add(hl.pd.plan ? hl.pd.image_bytes() : 0);
+    const size_t o_hinst = cv.add(hl.pd.plan ? hl.pd.inst_bytes(Cmax) : 0);
     void* ws = nullptr;
     rc = call_workspace(call, cv.total, &ws);
     if (rc) return rc;
@@ -1548,13 +1790,13 @@ int hbm_engine_run(const EvalCall& call) {
     double* partial = (double*)(w + o_part);
     if (pd.plan) {
         pd.buf = w + o_gate;
-        pd.mats = (double2*)(w + o_mats);
+        pd.carve(w + o_inst, Cmax);
         rc = upload_plan(call, pd);
         if (rc) return rc;
     }
     if (hl.pd.plan) {
         hl.pd.buf = w + o_hgate;
-        hl.pd.mats = (double2*)(w + o_hmats);
+        hl.pd.carve(w + o_hinst, Cmax);
         rc = upload_plan(call, hl.pd);
         if (rc) return rc;
     }
@@ -1590,14 +1832,10 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
         VQA_FAIL(VQA_EUNSUPPORTED, "HBM engine: n_marg_bits <= 10 (got %d)", call.n_marg_bits);
     PlanDev pd;
     pd.plan = &cone_plan_of(call);
-    pd.g = (size_t)call.c->n_ops;
     const TilePlan& plan = *pd.plan;
     HLayer hl;
     hl.mask = hlayer_mask(call);
-    if (hl.mask) {
-        hl.pd.plan = &hplan_of(call, hl.mask);
-        hl.pd.g = kHGates;
-    }
+    if (hl.mask) hl.pd.plan = &hplan_of(call, hl.mask);
     // the sweep plan's parameter lists without the parameters that cannot matter for this call's
     // observables (those join the ones that drive no gate: their rows are copies of row 0)
     ConeInfo& cone = *call.cone;
@@ -1651,13 +1889,13 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
     const size_t o_st = cv.add((size_t)(C + 3) * D * sizeof(double2));
     const size_t o_tab = cv.add((size_t)(C + 2) * n_ops * sizeof(double2));
     const size_t o_part = cv.add((size_t)C * nb * kZBatch * 2 * sizeof(double));
-    const size_t o_gate = cv.add(gate_buf_bytes(pd.g));
-    const size_t o_mats = cv.add(pd.mats_bytes(C + 2));
+    const size_t o_gate = cv.add(pd.image_bytes());
+    const size_t o_inst = cv.add(pd.inst_bytes(C + 2));
     const size_t o_ord = cv.add((size_t)std::max(m, 1) * sizeof(int32_t));
     const size_t o_coef = cv.add((size_t)std::max(m, 1) * sizeof(double));
     const size_t o_unused = cv.add((size_t)std::max(n_unused, 1) * sizeof(int32_t));
-    const size_t o_hgate = cv.add(hl.pd.plan ? gate_buf_bytes(hl.pd.g) : 0);
-    const size_t o_hmats = cv.add(hl.pd.plan ? hl.pd.mats_bytes(C) : 0);
+    const size_t o_hgate = cv.add(hl.pd.plan ? hl.pd.image_bytes() : 0);
+    const size_t o_hinst = cv.add(hl.pd.plan ? hl.pd.inst_bytes(C) : 0);
     void* ws = nullptr;
     rc = call_workspace(call, cv.total, &ws);
     if (rc) return rc;
@@ -1669,12 +1907,12 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
     double* d_coef = (double*)(w + o_coef);
     int32_t* d_unused = (int32_t*)(w + o_unused);
     pd.buf = w + o_gate;
-    pd.mats = (double2*)(w + o_mats);
+    pd.carve(w + o_inst, C + 2);
     rc = upload_plan(call, pd);
     if (rc) return rc;
     if (hl.pd.plan) {
         hl.pd.buf = w + o_hgate;
-        hl.pd.mats = (double2*)(w + o_hmats);
+        hl.pd.carve(w + o_hinst, C);
         rc = upload_plan(call, hl.pd);
         if (rc) return rc;
     }
@@ -1707,7 +1945,7 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
         if (h.n_ops > 0)
             hipLaunchKernelGGL(k_angles, dim3((unsigned)((h.n_ops + kT - 1) / kT)), dim3(kT), 0, call.stream, h, tab);
         launch_mats(call, pd, tab, h.n_ops, 0, 1);
-        launch_all_passes(call, pd, F, tab, h.n_ops, 0, 1);
+        launch_all_passes(call, pd, F, 0, 1);
         rc = measure_states(call, F, 1, row0, nb, partial, nullptr, hl);   // leaves F alone: the layer goes onto hl.alt
         if (rc) return rc;
         if (n_unused > 0) {
@@ -1731,7 +1969,7 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
             hipLaunchKernelGGL(k_sweep_angles, dim3((unsigned)((na + kT - 1) / kT)), dim3(kT), 0, call.stream, h, j,
                                d_ord + a, cnt + 2, tab);
             launch_mats(call, pd, tab, h.n_ops, 0, cnt + 2);
-            for (; rpass < k0; ++rpass) launch_pass(call, pd, rpass, R, tab + n_ops, h.n_ops, 1, 1);
+            for (; rpass < k0; ++rpass) launch_pass(call, pd, rpass, R, 1, 1);
             int live = 0;
             for (size_t k = k0; k < n_pass; ++k) {
                 int fresh = 0;
@@ -1741,10 +1979,10 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
                 live += fresh;
                 if (k < k1) {
                     // the running state moves on with the chunk while later passes still take copies of it
-                    launch_pass(call, pd, k, R, tab + n_ops, h.n_ops, 1, live + 1);
+                    launch_pass(call, pd, k, R, 1, live + 1);
                     rpass = k + 1;
                 } else {
-                    launch_pass(call, pd, k, S, tab + 2 * (size_t)n_ops, h.n_ops, 2, live);
+                    launch_pass(call, pd, k, S, 2, live);
                 }
             }
             PairArgs pa = { F, hl.alt, row0, d_ord + a, d_coef + a, call.spec.shift };
@@ -1753,6 +1991,16 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
         }
     }
     VQA_HIP(hipGetLastError());
+    if (getenv("VQA_PLAN_DEBUG")) {
+        fprintf(stderr, "[vqa] sweep of %d samples: %d live parameters, %zu passes, %lld state passes in all (%.1f per sample)\n",
+                n_samples, m, n_pass, (long long)t_state_passes, (double)t_state_passes / std::max(n_samples, 1));
+        for (size_t k = 0; k < n_pass; ++k) {
+            const auto& p = plan.passes[k];
+            fprintf(stderr, "[vqa]   pass %2zu: %3zu gates, %2zu sweeps (%zu with a diagonal run), %2zu fused 2x2, %3zu register ops, %zu late gates\n",
+                    k, p.gates.size(), p.sweeps.size(), p.runs.size(), p.mats.size(), p.ops.size(), p.xgates.size());
+        }
+        t_state_passes = 0;
+    }
     if (call.param_mask) VQA_HIP(hipStreamSynchronize(call.stream));
     return VQA_OK;
 }
@@ -1763,19 +2011,18 @@ int hbm_engine_statevector(const EvalCall& call, double* d_out_state) {
     PlanDev pd;
     if (tiled(call)) {
         pd.plan = &plan_of(call);
-        pd.g = (size_t)call.c->n_ops;
     }
     Carver cv;
     const size_t o_tab = cv.add((size_t)std::max(call.c->n_ops, 1) * sizeof(double2));
-    const size_t o_gate = cv.add(pd.plan ? gate_buf_bytes(pd.g) : 0);
-    const size_t o_mats = cv.add(pd.plan ? pd.mats_bytes(1) : 0);
+    const size_t o_gate = cv.add(pd.plan ? pd.image_bytes() : 0);
+    const size_t o_inst = cv.add(pd.plan ? pd.inst_bytes(1) : 0);
     void* ws = nullptr;
     int rc = call_workspace(call, cv.total, &ws);
     if (rc) return rc;
     char* w = (char*)ws;
     if (pd.plan) {
         pd.buf = w + o_gate;
-        pd.mats = (double2*)(w + o_mats);
+        pd.carve(w + o_inst, 1);
         rc = upload_plan(call, pd);
         if (rc) return rc;
     }
