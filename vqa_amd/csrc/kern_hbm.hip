@@ -31,9 +31,6 @@
 #ifndef VQA_TILE_BITS
 #define VQA_TILE_BITS 12
 #endif
-#ifndef VQA_TILES_PER_WG
-#define VQA_TILES_PER_WG 1
-#endif
 
 namespace vqa {
 
@@ -159,7 +156,6 @@ constexpr int kTileWaves = 2 * (kTT / 64) / 4; // waves per SIMD with two workgr
 #endif
 constexpr int kGateBatch = 256;               // most gates in one pass
 constexpr int kMaxSweeps = 64;                // most sweeps in one pass
-constexpr int kTilesPerWg = VQA_TILES_PER_WG;  // most tiles one workgroup runs one after the other
 // internal gate kinds (beside VQA_GATE_*)
 constexpr int kGateZZ = 9;                    // CNOT(c,t) RZ_t(a) CNOT(c,t) = exp(i a/2 Z_c Z_t), p0 = t, p1 = c
 constexpr int kGateU = 10;                    // a fused run of 1-qubit gates on one qubit with a dense 2x2, g = run number
@@ -209,13 +205,14 @@ struct SweepDesc {
     int32_t next_run;                         // the next diagonal run of the pass behind this sweep, -1: none
     int32_t x_begin, x_tab, x_count;          // late gates of the run (plan numbering): the first x_tab need the tile's outer
                                               // bits and go into the phase table, the others join the halves of the tile
+    int32_t nx_begin, nx_tab;                 // x_begin, x_tab of next_run
 };
 // What the pass kernel reads per instance, written by the k_prep_* kernels: everything a
 // workgroup needs besides the amplitudes is the same for all its threads, so it sits in
 // global memory in the order of use and arrives through the scalar data cache.
 struct OpRec {                                // one register operation
     double t, u;                              // rotation: tan(phi / 2), sin(phi) of the normal form
-    int32_t code;                             // bit slot: rotation on that group slot, bit 4 + slot: CNOT onto it, bit 8: diag(1, b1) first
+    int32_t code;                             // bit slot: rotation on that group slot, bit 4 + slot: CNOT onto it, bit 8: diag(1, b1) first, bit 9: the two-shear form, bit 10: the three-shear form
     int32_t ctrl;                             // CNOT: control position
     int32_t pad[2];
     double2 b1;
@@ -231,8 +228,8 @@ struct TilePassArgs {
     int oq[32];                               // outer bit number -> qubit (ascending)
     int n_outer;
     int n_sweeps, first_run;                  // this pass
+    int first_xb, first_xt;                   // x_begin, x_tab of first_run
     int n_ops_total, n_runs_total, n_x_total; // row lengths of the per-instance tables
-    int tiles_per_wg;
 #ifdef VQA_TILE_ABLATE
     int ablate;                               // timing experiments (libvqahip_abl.so): bit 0 no sweeps, 1 no LDS traffic in the sweeps, 2 no register operations, 3 no diagonal runs
 #endif
@@ -260,7 +257,7 @@ __device__ __forceinline__ bool gate_bit(int p, int64_t base, int i) {
 __device__ __forceinline__ int tile_slot(int i) { return i ^ ((i >> 4) & 15) ^ ((i >> 8) & 15); }
 
 // the product of the 1-qubit gates [begin, begin + count) for every instance, in normal form:
-// mats[(ci * M + m) * 4 ..] = (tan(phi / 2), sin(phi)), A0, A1, b1
+// mats[(ci * M + m) * 4 ..] = (tan(phi / 2), sin(phi)) or (-s / c, s c), A0, A1, b1
 __global__ __launch_bounds__(kT) void k_mats(const TileGate* __restrict__ gates, const MatDesc* __restrict__ descs, int M,
                                              const double2* __restrict__ tab, int n_ops, int C, double2* __restrict__ mats) {
     const int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;
@@ -312,7 +309,16 @@ __global__ __launch_bounds__(kT) void k_mats(const TileGate* __restrict__ gates,
             b1 = { 1.0, 0.0 };
         }
     }
-    const double t = s / (1.0 + c), u = s;   // tan(phi / 2), sin(phi)
+    double t = s / (1.0 + c), u = s;   // tan(phi / 2), sin(phi)
+    if (c >= 0.5) {
+        // two shears are enough up to the scales 1 / c and c, which A0 and A1 take over: a1 += (s / c) a0,
+        // a0 -= (s c) a1.  (The first component comes out of a difference that leaves c^2 of it, so
+        // the form is kept to angles where that costs two bits at most.)  Marked by a negative t.
+        t = -(s / c);
+        u = s * c;
+        A0 = { A0.x / c, A0.y / c };
+        A1 = { A1.x * c, A1.y * c };
+    }
     double2* o = mats + i * 4;
     o[0] = make_double2(t, u);
     o[1] = d2of(A0);
@@ -346,10 +352,10 @@ __global__ __launch_bounds__(kT) void k_prep_ops(const GroupOp* __restrict__ ops
     r.b1 = make_double2(1.0, 0.0);
     if (op.type == OP_ROT) {
         const double2* m = mats + ((int64_t)ci * M + op_mat0[o] + op.a) * 4;
-        r.t = m[0].x;
+        r.t = fabs(m[0].x);
         r.u = m[0].y;
         r.b1 = m[3];
-        r.code = (1 << op.slot) | (op.b ? 256 : 0);
+        r.code = (1 << op.slot) | (op.b ? 256 : 0) | (m[0].x < 0.0 ? 512 : 1024);
     } else {
         r.code = 16 << op.slot;
         r.ctrl = op.a;
@@ -427,6 +433,14 @@ __device__ __forceinline__ void shear_quad(double& a0, double& a1, double& b0, d
         : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "+v"(c0), "+v"(c1), "+v"(d0), "+v"(d1)
         : "s"(t), "s"(u));
 }
+//   the two-shear form: a1 += t a0, a0 -= u a1
+__device__ __forceinline__ void shear2_quad(double& a0, double& a1, double& b0, double& b1, double& c0, double& c1,
+                                            double& d0, double& d1, double t, double u) {
+    asm("v_fma_f64 %1, %8, %0, %1\n\tv_fma_f64 %3, %8, %2, %3\n\tv_fma_f64 %5, %8, %4, %5\n\tv_fma_f64 %7, %8, %6, %7\n\t"
+        "v_fma_f64 %0, -%9, %1, %0\n\tv_fma_f64 %2, -%9, %3, %2\n\tv_fma_f64 %4, -%9, %5, %4\n\tv_fma_f64 %6, -%9, %7, %6"
+        : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "+v"(c0), "+v"(c1), "+v"(d0), "+v"(d1)
+        : "s"(t), "s"(u));
+}
 //   (ax + i ay) <- (ax + i ay) (tx + i ty)
 __device__ __forceinline__ void cmul_inplace(double& ax, double& ay, double tx, double ty) {
     double t1, t2;
@@ -444,19 +458,29 @@ __device__ __forceinline__ void cswap_inplace(double& a, double& b, double m0, d
 
 // the rotation of a fused 2x2 on group slot J (see "Normal form"); pre: diag(1, b1) first
 template <int J>
-__device__ __forceinline__ void apply_rot(double2 (&a)[kTA], double t, double u, bool pre, c2 b1) {
-    if (pre) {
+__device__ __forceinline__ void apply_rot(double2 (&a)[kTA], double t, double u, int code, c2 b1) {
+    if (code & 256) {
 #pragma unroll
         for (int r = 0; r < kTA; ++r)
             if (r & (1 << J)) cmul_inplace(a[r].x, a[r].y, b1.x, b1.y);
     }
-    // the pairs of slot J, two at a time
+    // the pairs of slot J, two at a time; the two forms are separate blocks (not an if / else)
     constexpr int lo = (1 << J) - 1;
+    if (code & 1024) {
 #pragma unroll
-    for (int q = 0; q < kTA / 2; q += 2) {
-        const int r0 = ((q & ~lo) << 1) | (q & lo), r1 = (((q + 1) & ~lo) << 1) | ((q + 1) & lo);
-        shear_quad(a[r0].x, a[r0 | (1 << J)].x, a[r0].y, a[r0 | (1 << J)].y, a[r1].x, a[r1 | (1 << J)].x, a[r1].y,
-                   a[r1 | (1 << J)].y, t, u);
+        for (int q = 0; q < kTA / 2; q += 2) {
+            const int r0 = ((q & ~lo) << 1) | (q & lo), r1 = (((q + 1) & ~lo) << 1) | ((q + 1) & lo);
+            shear_quad(a[r0].x, a[r0 | (1 << J)].x, a[r0].y, a[r0 | (1 << J)].y, a[r1].x, a[r1 | (1 << J)].x, a[r1].y,
+                       a[r1 | (1 << J)].y, t, u);
+        }
+    }
+    if (code & 512) {
+#pragma unroll
+        for (int q = 0; q < kTA / 2; q += 2) {
+            const int r0 = ((q & ~lo) << 1) | (q & lo), r1 = (((q + 1) & ~lo) << 1) | ((q + 1) & lo);
+            shear2_quad(a[r0].x, a[r0 | (1 << J)].x, a[r0].y, a[r0 | (1 << J)].y, a[r1].x, a[r1 | (1 << J)].x, a[r1].y,
+                        a[r1 | (1 << J)].y, t, u);
+        }
     }
 }
 
@@ -487,28 +511,46 @@ __device__ __forceinline__ uint32_t tile_base(const TilePassArgs& a, uint32_t w)
 // (blocks, not a switch: each block then updates the amplitudes in place, and they stay in one
 // set of registers around the loop over the operations)
 __device__ __forceinline__ void apply_op(double2 (&v)[kTA], const OpRec& r, int64_t base, int ib, const int (&off)[kTA]) {
-    const bool pre = (r.code & 256) != 0;
     const c2 b1 = c2of(r.b1);
-    if (r.code & 1) apply_rot<0>(v, r.t, r.u, pre, b1);
-    if (r.code & 2) apply_rot<1>(v, r.t, r.u, pre, b1);
-    if (r.code & 4) apply_rot<2>(v, r.t, r.u, pre, b1);
-    if (kGroup > 3 && (r.code & 8)) apply_rot<kGroup - 1>(v, r.t, r.u, pre, b1);
+    if (r.code & 1) apply_rot<0>(v, r.t, r.u, r.code, b1);
+    if (r.code & 2) apply_rot<1>(v, r.t, r.u, r.code, b1);
+    if (r.code & 4) apply_rot<2>(v, r.t, r.u, r.code, b1);
+    if (kGroup > 3 && (r.code & 8)) apply_rot<kGroup - 1>(v, r.t, r.u, r.code, b1);
     if (r.code & 16) apply_cnot<0>(v, r.ctrl, base, ib, off);
     if (r.code & 32) apply_cnot<1>(v, r.ctrl, base, ib, off);
     if (r.code & 64) apply_cnot<2>(v, r.ctrl, base, ib, off);
     if (kGroup > 3 && (r.code & 128)) apply_cnot<kGroup - 1>(v, r.ctrl, base, ib, off);
 }
 
-// One workgroup runs the pass on `tiles_per_wg` tiles of one instance, one after the other:
-// the next tile's amplitudes are fetched from HBM while the sweeps of the current one run.
+constexpr int kFusedZ = 8;   // most Z-strings / marginal bins the last pass of a sweep measures itself
+
+// Where the states of a launch are read and written, and what the pass measures at its end.
+struct PassIO {
+    const double2* alt_src;   // states ci >= alt_from are read from here: the running unshifted state they branch off
+    int alt_from;
+    const double2* rd0;       // state 0 is read from here (nullptr: from its own place)
+    double2* wr0;             // state 0 is written here (nullptr: to its own place)
+    // MEAS: per Z-string (or marginal bin) the tile's sums of sign |phi|^2 and sign Re(conj(psi) phi), psi = F,
+    // to partial[((ci * n_tiles + tile) * kZBatch + t) * 2 + {0, 1}] (what k_zpart2 writes per block)
+    const double2* F;
+    double* partial;
+    int nz, write_state;
+    uint32_t z[kFusedZ];
+    int32_t bin[kFusedZ];     // < 0: Z-string z (a sign); >= 0: the indicator of (index & z) == bin
+};
+
+// One workgroup runs the pass on one tile of one instance.
+template <int MEAS>
 __global__ __launch_bounds__(kTT, kTileWaves) void k_tile_pass(double2* __restrict__ st, const SweepDesc* __restrict__ sweeps,
                                                    const OpRec* __restrict__ oprec, const double2* __restrict__ pretab,
-                                                   const XRec* __restrict__ xrec, TilePassArgs a) {
+                                                   const XRec* __restrict__ xrec, TilePassArgs a, PassIO io) {
     extern __shared__ double2 tile[];
-    __shared__ double2 dtab[128];
+    __shared__ double2 dtab[2][128];   // the phase tables of the current diagonal run and of the next one
     const int tid = threadIdx.x;
     const int ci = blockIdx.y;
-    double2* s = st + ((int64_t)ci << a.n);
+    double2* own = st + ((int64_t)ci << a.n);
+    const double2* s = ci >= io.alt_from ? io.alt_src : (ci == 0 && io.rd0) ? io.rd0 : own;
+    double2* sout = (ci == 0 && io.wr0) ? io.wr0 : own;
     const OpRec* __restrict__ my_ops = oprec + (int64_t)ci * a.n_ops_total;
     const double2* __restrict__ my_tab = pretab + (int64_t)ci * a.n_runs_total * 128;
     const XRec* __restrict__ my_x = xrec + (int64_t)ci * a.n_x_total;
@@ -524,65 +566,46 @@ __global__ __launch_bounds__(kTT, kTileWaves) void k_tile_pass(double2* __restri
 #pragma unroll
         for (int j = kThreadBits; j < kTileBits; ++j) g_k[k] |= (uint32_t)((k >> (j - kThreadBits)) & 1) << a.tq[j];
     }
-    const uint32_t w0 = blockIdx.x * (uint32_t)a.tiles_per_wg;
-    // the prefetched tile, as one vector value (an array carried around the tile loop would live in scratch)
-    typedef double pvec_t __attribute__((ext_vector_type(2 * kTA)));
-    pvec_t pv;
-    {
-        const uint32_t b0 = tile_base(a, w0);
+    const uint32_t base = tile_base(a, blockIdx.x);
+    double2 pv[kTA];
 #pragma unroll
-        for (int k = 0; k < kTA; ++k) {
-            const double2 t2 = s[b0 | g_tid | g_k[k]];
-            pv[2 * k] = t2.x;
-            pv[2 * k + 1] = t2.y;
-        }
-    }
+    for (int k = 0; k < kTA; ++k) pv[k] = s[base | g_tid | g_k[k]];
 #ifdef VQA_TILE_ABLATE
     const int abl = a.ablate;
 #else
     constexpr int abl = 0;
 #endif
-    for (int t = 0; t < (kTilesPerWg > 1 ? a.tiles_per_wg : 1); ++t) {
-        const uint32_t base = tile_base(a, w0 + t);
-        // this thread's entry of the next diagonal run's tables, fetched a run ahead
+    {
+        // The phase of amplitude i of a diagonal run factors into a part from its low six tile bits (and
+        // the outer bits, fixed here), a part from its high six, and the gates that join the two halves.
+        // The parts come from the instance's tables; the late gates that involve an outer qubit are
+        // applied to them here.  The tables of a run are put together a run ahead: the entry is
+        // fetched at the start of the sweep of the run before and finished at its end.
+        auto finish_table = [&](double2 entry, int xb, int xt, double2* dst) {
+            const int half = tid >> 6, i = half ? (tid & 63) << 6 : (tid & 63);
+            c2 ph = c2of(entry);
+            for (int k = xb; k < xb + xt; ++k) {
+                const XRec x = my_x[k];
+                const int tp = x.p0 < 32 ? x.p0 : x.p1;   // the tile position it acts on, if any
+                if ((int)(tp < 32 && tp >= 6) != half) continue;
+                const bool b0 = gate_bit(x.p0, base, i), b1 = gate_bit(x.p1, base, i);
+                const bool sel = (x.mode & 2) ? (b0 && b1) : (x.mode & 1) ? (b0 != b1) : b0;
+                ph = cm(ph, c2of(sel ? x.v1 : x.v0));
+            }
+            dst[tid] = d2of(ph);
+        };
         double2 ahead = make_double2(1.0, 0.0);
         if (a.first_run >= 0 && tid < 128) ahead = my_tab[a.first_run * 128 + tid];
-        lds_barrier();   // the previous tile has left LDS
 #pragma unroll
-        for (int k = 0; k < kTA; ++k) tile[tile_slot(k * kTT + tid)] = make_double2(pv[2 * k], pv[2 * k + 1]);
-        if (kTilesPerWg > 1 && t + 1 < a.tiles_per_wg) {
-            const uint32_t b1 = tile_base(a, w0 + t + 1);
-#pragma unroll
-            for (int k = 0; k < kTA; ++k) {
-                const double2 t2 = s[b1 | g_tid | g_k[k]];
-                pv[2 * k] = t2.x;
-                pv[2 * k + 1] = t2.y;
-            }
-        }
+        for (int k = 0; k < kTA; ++k) tile[tile_slot(k * kTT + tid)] = pv[k];
+        if (a.first_run >= 0 && tid < 128) finish_table(ahead, a.first_xb, a.first_xt, dtab[0]);
+        int cur = 0;   // which table the next diagonal run reads
         for (int si = 0; si < ((abl & 1) ? 0 : a.n_sweeps); ++si) {
-            lds_barrier();   // the previous sweep's amplitudes (or the gathered tile) are in LDS, its phase table has been read
+            lds_barrier();   // the previous sweep's amplitudes (or the gathered tile) and the next table are in LDS
             const SweepDesc sw = sweeps[si];
-            if (sw.run >= 0) {
-                if (tid < 128) {
-                    // The phase of amplitude i factors into a part from its low six tile bits (and the
-                    // outer bits, fixed here), a part from its high six, and the gates that join the
-                    // two halves.  The parts come from the instance's tables; the gates that involve an
-                    // outer qubit are applied here.
-                    const int half = tid >> 6, i = half ? (tid & 63) << 6 : (tid & 63);
-                    c2 ph = c2of(ahead);
-                    if (sw.next_run >= 0) ahead = my_tab[sw.next_run * 128 + tid];
-                    for (int k = sw.x_begin; k < sw.x_begin + sw.x_tab; ++k) {
-                        const XRec x = my_x[k];
-                        const int tp = x.p0 < 32 ? x.p0 : x.p1;   // the tile position it acts on, if any
-                        if ((int)(tp < 32 && tp >= 6) != half) continue;
-                        const bool b0 = gate_bit(x.p0, base, i), b1 = gate_bit(x.p1, base, i);
-                        const bool sel = (x.mode & 2) ? (b0 && b1) : (x.mode & 1) ? (b0 != b1) : b0;
-                        ph = cm(ph, c2of(sel ? x.v1 : x.v0));
-                    }
-                    dtab[tid] = d2of(ph);
-                }
-                lds_barrier();
-            }
+            const bool table_next = sw.run >= 0 && sw.next_run >= 0 && tid < 128;
+            if (table_next) ahead = my_tab[sw.next_run * 128 + tid];
+            const double2* dt = dtab[cur];
             // this thread's amplitudes: thread bits on tpos, register bits on gpos
             int ib = 0;
 #pragma unroll
@@ -613,17 +636,16 @@ __global__ __launch_bounds__(kTT, kTileWaves) void k_tile_pass(double2* __restri
                 // records are fetched together
                 const OpRec r0 = my_ops[max(sw.rot[0], 0)], r1 = my_ops[max(sw.rot[1], 0)], r2 = my_ops[max(sw.rot[2], 0)],
                             r3 = my_ops[max(sw.rot[kGroup - 1], 0)];
-                if (sw.rot[0] >= 0) apply_rot<0>(v, r0.t, r0.u, (r0.code & 256) != 0, c2of(r0.b1));
-                if (sw.rot[1] >= 0) apply_rot<1>(v, r1.t, r1.u, (r1.code & 256) != 0, c2of(r1.b1));
-                if (sw.rot[2] >= 0) apply_rot<2>(v, r2.t, r2.u, (r2.code & 256) != 0, c2of(r2.b1));
-                if (kGroup > 3 && sw.rot[kGroup - 1] >= 0)
-                    apply_rot<kGroup - 1>(v, r3.t, r3.u, (r3.code & 256) != 0, c2of(r3.b1));
+                if (sw.rot[0] >= 0) apply_rot<0>(v, r0.t, r0.u, r0.code, c2of(r0.b1));
+                if (sw.rot[1] >= 0) apply_rot<1>(v, r1.t, r1.u, r1.code, c2of(r1.b1));
+                if (sw.rot[2] >= 0) apply_rot<2>(v, r2.t, r2.u, r2.code, c2of(r2.b1));
+                if (kGroup > 3 && sw.rot[kGroup - 1] >= 0) apply_rot<kGroup - 1>(v, r3.t, r3.u, r3.code, c2of(r3.b1));
             }
             if (sw.run >= 0 && !(abl & 8)) {
 #pragma unroll
                 for (int r = 0; r < kTA; ++r) {
                     const int i = ib | off[r];
-                    const c2 ph = cm(c2of(dtab[i & 63]), c2of(dtab[64 + (i >> 6)]));
+                    const c2 ph = cm(c2of(dt[i & 63]), c2of(dt[64 + (i >> 6)]));
                     cmul_inplace(v[r].x, v[r].y, ph.x, ph.y);
                     if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four amplitudes' table reads in flight, not all
                 }
@@ -658,10 +680,73 @@ __global__ __launch_bounds__(kTT, kTileWaves) void k_tile_pass(double2* __restri
 #pragma unroll
                 for (int r = 0; r < kTA; ++r) tile[sb ^ tile_slot(off[r])] = v[r];
             }
+            if (table_next) finish_table(ahead, sw.nx_begin, sw.nx_tab, dtab[cur ^ 1]);
+            if (sw.run >= 0) cur ^= 1;
+        }
+        if (MEAS) {
+#pragma unroll
+            for (int k = 0; k < kTA; ++k) pv[k] = io.F[base | g_tid | g_k[k]];   // psi, on its way during the barrier
         }
         lds_barrier();
+        if (!MEAS || io.write_state) {
 #pragma unroll
-        for (int k = 0; k < kTA; ++k) s[base | g_tid | g_k[k]] = tile[tile_slot(k * kTT + tid)];
+            for (int k = 0; k < kTA; ++k) sout[base | g_tid | g_k[k]] = tile[tile_slot(k * kTT + tid)];
+        }
+        if (MEAS) {
+            // The index bits that differ between a thread's amplitudes are the four highest tile
+            // positions; an entry whose mask avoids them has one sign (or bin test) per thread and is
+            // applied to the thread's plain sums.
+            const uint32_t vary = g_k[kTA - 1];
+            double tot = 0.0, totx = 0.0, acc[kFusedZ], acx[kFusedZ];
+#pragma unroll
+            for (int t = 0; t < kFusedZ; ++t) acc[t] = acx[t] = 0.0;
+#pragma unroll
+            for (int k = 0; k < kTA; ++k) {
+                const double2 phi = tile[tile_slot(k * kTT + tid)], psi = pv[k];
+                const double pr = phi.x * phi.x + phi.y * phi.y, cr = psi.x * phi.x + psi.y * phi.y;
+                const uint32_t idx = base | g_tid | g_k[k];
+                tot += pr;
+                totx += cr;
+#pragma unroll
+                for (int t = 0; t < kFusedZ; ++t) {
+                    if (t < io.nz && (io.z[t] & vary)) {
+                        const bool on = io.bin[t] >= 0 ? (idx & io.z[t]) == (uint32_t)io.bin[t] : !(__popc(idx & io.z[t]) & 1);
+                        const double sg = io.bin[t] >= 0 ? (on ? 1.0 : 0.0) : (on ? 1.0 : -1.0);
+                        acc[t] += sg * pr;
+                        acx[t] += sg * cr;
+                    }
+                }
+            }
+            __shared__ double red[2 * kFusedZ][kTT / 64];
+            const uint32_t idx0 = base | g_tid;
+#pragma unroll
+            for (int t = 0; t < kFusedZ; ++t) {
+                if (t < io.nz) {
+                    if (!(io.z[t] & vary)) {
+                        const bool on = io.bin[t] >= 0 ? (idx0 & io.z[t]) == (uint32_t)io.bin[t] : !(__popc(idx0 & io.z[t]) & 1);
+                        const double sg = io.bin[t] >= 0 ? (on ? 1.0 : 0.0) : (on ? 1.0 : -1.0);
+                        acc[t] = sg * tot;
+                        acx[t] = sg * totx;
+                    }
+                    double va = acc[t], vx = acx[t];
+                    for (int o = 32; o > 0; o >>= 1) {
+                        va += __shfl_down(va, o, 64);
+                        vx += __shfl_down(vx, o, 64);
+                    }
+                    if ((tid & 63) == 0) {
+                        red[2 * t][tid >> 6] = va;
+                        red[2 * t + 1][tid >> 6] = vx;
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid < 2 * io.nz) {
+                double r = 0.0;
+#pragma unroll
+                for (int w = 0; w < kTT / 64; ++w) r += red[tid][w];
+                io.partial[(((int64_t)ci * gridDim.x + blockIdx.x) * kZBatch + (tid >> 1)) * 2 + (tid & 1)] = r;
+            }
+        }
     }
 }
 
@@ -697,6 +782,7 @@ struct TilePlan {
     std::vector<SweepDesc> all_sweeps;
     std::vector<size_t> soff;          // where each pass's sweeps start
     std::vector<int> first_run;        // each pass's first diagonal run (plan numbering), -1: none
+    std::vector<int> first_xb, first_xt;   // and its late gates (x_begin, x_tab)
     std::vector<int> pass_of_gate;     // gate index -> the pass that runs it
     // parameter-shift sweeps (filled by plan_sweep): the parameters that drive exactly one
     // rotation, ordered by the pass of that rotation, and the ones that drive none
@@ -850,9 +936,16 @@ static bool group_sweeps(TilePlan::Pass& pass, const std::vector<TileGate>& in_o
         }
         pass.sweeps.push_back(sd);
     }
-    for (int si = (int)pass.sweeps.size() - 1, nxt = -1; si >= 0; --si) {
-        pass.sweeps[si].next_run = nxt;
-        if (pass.sweeps[si].run >= 0) nxt = pass.sweeps[si].run;
+    for (int si = (int)pass.sweeps.size() - 1, nxt = -1, nxb = 0, nxt_tab = 0; si >= 0; --si) {
+        SweepDesc& sd = pass.sweeps[si];
+        sd.next_run = nxt;
+        sd.nx_begin = nxb;
+        sd.nx_tab = nxt_tab;
+        if (sd.run >= 0) {
+            nxt = sd.run;
+            nxb = sd.x_begin;
+            nxt_tab = sd.x_tab;
+        }
     }
     pass.gates.insert(pass.gates.end(), cnot_gates.begin(), cnot_gates.end());
     const int run_base = (int)pass.gates.size();
@@ -981,10 +1074,19 @@ static TilePlan plan_tiles(int n, const std::vector<vqa_op>& ops, const std::vec
             if (sd.run >= 0) sd.run += rbase;
             if (sd.next_run >= 0) sd.next_run += rbase;
             sd.x_begin += xbase;
-            if (first < 0 && sd.run >= 0) first = sd.run;
+            sd.nx_begin += xbase;
+            if (first < 0 && sd.run >= 0) {
+                first = sd.run;
+                plan.first_xb.push_back(sd.x_begin);
+                plan.first_xt.push_back(sd.x_tab);
+            }
             plan.all_sweeps.push_back(sd);
         }
         plan.first_run.push_back(first);
+        if (first < 0) {
+            plan.first_xb.push_back(0);
+            plan.first_xt.push_back(0);
+        }
     }
     return plan;
 }
@@ -1476,7 +1578,9 @@ int upload_plan(const EvalCall& call, const PlanDev& pd) {
     VQA_HIP(up(im.mats, plan.all_mats.data(), plan.all_mats.size() * sizeof(MatDesc)));
     VQA_HIP(up(im.runs, plan.all_runs.data(), plan.all_runs.size() * sizeof(RunDesc)));
     VQA_HIP(up(im.sweeps, plan.all_sweeps.data(), plan.all_sweeps.size() * sizeof(SweepDesc)));
-    VQA_HIP(hipFuncSetAttribute((const void*)k_tile_pass, hipFuncAttributeMaxDynamicSharedMemorySize,
+    VQA_HIP(hipFuncSetAttribute((const void*)k_tile_pass<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                kTileAmps * (int)sizeof(double2)));
+    VQA_HIP(hipFuncSetAttribute((const void*)k_tile_pass<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 kTileAmps * (int)sizeof(double2)));
     return VQA_OK;
 }
@@ -1505,8 +1609,9 @@ void launch_mats(const EvalCall& call, const PlanDev& pd, const double2* tab, in
 
 thread_local int64_t t_state_passes = 0;   // states x passes launched by this thread (VQA_PLAN_DEBUG report)
 
-// pass k of the plan on C states side by side (st; table rows slot0 .. of the per-instance tables)
-void launch_pass(const EvalCall& call, const PlanDev& pd, size_t k, double2* st, int slot0, int C) {
+// pass k of the plan on C states side by side (st; table rows slot0 .. of the per-instance tables);
+// io (may be null): other sources / destinations of some states, a measurement at the end
+void launch_pass(const EvalCall& call, const PlanDev& pd, size_t k, double2* st, int slot0, int C, const PassIO* io = nullptr) {
     const TilePlan& plan = *pd.plan;
     const auto& p = plan.passes[k];
     if (p.sweeps.empty() || C <= 0) return;
@@ -1524,20 +1629,29 @@ void launch_pass(const EvalCall& call, const PlanDev& pd, size_t k, double2* st,
     for (int t = 0; t < kTileBits; ++t) a.tq[t] = p.tq[t];
     a.n_sweeps = (int)p.sweeps.size();
     a.first_run = plan.first_run[k];
+    a.first_xb = plan.first_xb[k];
+    a.first_xt = plan.first_xt[k];
     a.n_ops_total = (int)pd.n_ops();
     a.n_runs_total = (int)pd.n_runs();
     a.n_x_total = (int)pd.n_x();
-    const int64_t D = (int64_t)1 << n;
-    // enough workgroups to fill the GPU a few times over, else several tiles per workgroup
-    const int64_t n_tiles = D >> kTileBits;
-    int tpw = 1;
-    while (tpw < kTilesPerWg && n_tiles % (2 * tpw) == 0 && (n_tiles / (2 * tpw)) * C >= 2048) tpw *= 2;
-    a.tiles_per_wg = tpw;
+    const int64_t n_tiles = ((int64_t)1 << n) >> kTileBits;
 #ifdef VQA_TILE_ABLATE
     a.ablate = getenv("VQA_TILE_ABLATE") ? atoi(getenv("VQA_TILE_ABLATE")) : 0;
 #endif
-    hipLaunchKernelGGL(k_tile_pass, dim3((unsigned)(n_tiles / tpw), C), dim3(kTT), kTileAmps * sizeof(double2),
-                       call.stream, st, im.sweeps + plan.soff[k], pd.oprec(slot0), pd.pretab(slot0), pd.xrec(slot0), a);
+    PassIO pio;
+    if (io) {
+        pio = *io;
+    } else {
+        memset(&pio, 0, sizeof(pio));
+        pio.alt_from = 1 << 30;
+    }
+    const dim3 grid((unsigned)n_tiles, C);
+    if (pio.nz > 0)
+        hipLaunchKernelGGL(k_tile_pass<1>, grid, dim3(kTT), kTileAmps * sizeof(double2), call.stream, st,
+                           im.sweeps + plan.soff[k], pd.oprec(slot0), pd.pretab(slot0), pd.xrec(slot0), a, pio);
+    else
+        hipLaunchKernelGGL(k_tile_pass<0>, grid, dim3(kTT), kTileAmps * sizeof(double2), call.stream, st,
+                           im.sweeps + plan.soff[k], pd.oprec(slot0), pd.pretab(slot0), pd.xrec(slot0), a, pio);
 }
 
 void launch_all_passes(const EvalCall& call, const PlanDev& pd, double2* st, int slot0, int C) {
@@ -1597,8 +1711,11 @@ struct HLayer {
     double2* alt = nullptr;
 };
 
+// fused_nb > 0 (pairs, see fused_batch): the last pass has written the partial sums of the one batch
+// itself, fused_nb of them per state.
 int measure_states(const EvalCall& call, double2* st, int C, int64_t e0, int nb, double* partial,
-                   const PairArgs* pair, const HLayer& hl) {
+                   const PairArgs* pair, const HLayer& hl, int fused_nb = 0) {
+    if (fused_nb > 0) nb = fused_nb;
     const int n = call.c->n_qubits;
     const int n_obs = call.obs.n_obs;
     if (n_obs > 0) {
@@ -1630,7 +1747,8 @@ int measure_states(const EvalCall& call, double2* st, int C, int64_t e0, int nb,
         }
         if (zb.nz == 0) return;
         if (pair) {
-            if (zb.nz <= 8) hipLaunchKernelGGL(k_zpart2<8>, dim3(C, nb), dim3(kT), 0, call.stream, f, states, n, zb, partial);
+            if (fused_nb > 0) {}
+            else if (zb.nz <= 8) hipLaunchKernelGGL(k_zpart2<8>, dim3(C, nb), dim3(kT), 0, call.stream, f, states, n, zb, partial);
             else hipLaunchKernelGGL(k_zpart2<kZBatch>, dim3(C, nb), dim3(kT), 0, call.stream, f, states, n, zb, partial);
             if (nzs)
                 hipLaunchKernelGGL(k_finish2, dim3(C), dim3(kT), 0, call.stream, partial, nb, nzs, zb, 1, 0.0,
@@ -1729,6 +1847,29 @@ int measure_states(const EvalCall& call, double2* st, int C, int64_t e0, int nb,
     }
     VQA_HIP(hipGetLastError());
     return VQA_OK;
+}
+
+// The one batch of Z-strings and marginal bins of a call, in the order measure_states() puts them
+// together, when that is all the call measures and the last pass of a sweep can take it: false otherwise.
+bool fused_batch(const EvalCall& call, const HLayer& hl, int64_t n_tiles, int nb, PassIO* io) {
+    if (hl.pd.plan || n_tiles > nb || getenv("VQA_NO_FUSED_MEASURE")) return false;
+    const int M = call.n_marg_bits > 0 ? 1 << call.n_marg_bits : 0;
+    int nz = 0;
+    for (int t = 0; t < call.obs.n_terms; ++t) {
+        if (call.obs.x[t] != 0) return false;
+        if (nz < kFusedZ) {
+            io->z[nz] = (uint32_t)call.obs.z[t];
+            io->bin[nz] = -1;
+        }
+        ++nz;
+    }
+    if (nz + M > kFusedZ || nz + M == 0) return false;
+    for (int m = 0; m < M; ++m) {
+        io->z[nz + m] = (uint32_t)(M - 1);
+        io->bin[nz + m] = m;
+    }
+    io->nz = nz + M;
+    return true;
 }
 
 }  // namespace
@@ -1880,13 +2021,15 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
     int64_t Cmax;
     int nb;
     // slot 0: unshifted final state, slot 1: running unshifted state, slots 2 ..: one per parameter,
-    // behind them the unshifted final state with the Hadamard layer applied (when in use)
+    // behind them the unshifted final state with the Hadamard layer applied (when in use) and the
+    // second place of the running state (a pass reads it in one place and writes it to the other,
+    // so that the states that branch off in the same launch read it as it was)
     int rc = chunk_plan(call, 0.6, (size_t)200 << 30, Cmax, nb);
     if (rc) return rc;
-    if (Cmax < 4) VQA_FAIL(VQA_ENOMEM, "not enough free device memory for four %d-qubit states", n);
-    const int C = (int)std::min<int64_t>(Cmax - 3, std::max(m, 1));
+    if (Cmax < 5) VQA_FAIL(VQA_ENOMEM, "not enough free device memory for five %d-qubit states", n);
+    const int C = (int)std::min<int64_t>(Cmax - 4, std::max(m, 1));
     Carver cv;
-    const size_t o_st = cv.add((size_t)(C + 3) * D * sizeof(double2));
+    const size_t o_st = cv.add((size_t)(C + 4) * D * sizeof(double2));
     const size_t o_tab = cv.add((size_t)(C + 2) * n_ops * sizeof(double2));
     const size_t o_part = cv.add((size_t)C * nb * kZBatch * 2 * sizeof(double));
     const size_t o_gate = cv.add(pd.image_bytes());
@@ -1927,6 +2070,7 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
     double2* R = st + D;
     double2* S = st + 2 * D;
     hl.alt = st + (int64_t)(C + 2) * D;   // the unshifted final state behind the Hadamard layer
+    double2* R2 = st + (int64_t)(C + 3) * D;
     const unsigned gD = (unsigned)((D + kT - 1) / kT);
     HbmCommon h;
     h.n = n;
@@ -1961,6 +2105,7 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
         if (m == 0) continue;
         // the parameters, a chunk of slots at a time, in the order of the passes that hold their rotations
         hipLaunchKernelGGL(k_init, dim3(gD), dim3(kT), 0, call.stream, R, D, D);
+        double2* Rcur = R;
         size_t rpass = 0;
         for (int a = 0; a < m; a += C) {
             const int cnt = std::min(C, m - a);
@@ -1969,24 +2114,39 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
             hipLaunchKernelGGL(k_sweep_angles, dim3((unsigned)((na + kT - 1) / kT)), dim3(kT), 0, call.stream, h, j,
                                d_ord + a, cnt + 2, tab);
             launch_mats(call, pd, tab, h.n_ops, 0, cnt + 2);
-            for (; rpass < k0; ++rpass) launch_pass(call, pd, rpass, R, 1, 1);
+            for (; rpass < k0; ++rpass) launch_pass(call, pd, rpass, Rcur, 1, 1);
             int live = 0;
+            bool fused = false;
             for (size_t k = k0; k < n_pass; ++k) {
+                // the states whose rotation sits in this pass branch off the running state: they read it
                 int fresh = 0;
                 while (live + fresh < cnt && (size_t)ord_pass[a + live + fresh] == k) ++fresh;
-                if (fresh > 0)
-                    hipLaunchKernelGGL(k_spawn, dim3(gD), dim3(kT), 0, call.stream, S + (int64_t)live * D, R, D, fresh);
-                live += fresh;
+                PassIO io;
+                memset(&io, 0, sizeof(io));
+                io.alt_src = Rcur;
                 if (k < k1) {
-                    // the running state moves on with the chunk while later passes still take copies of it
-                    launch_pass(call, pd, k, R, 1, live + 1);
+                    // the running state moves on with the chunk while later passes still branch off it
+                    io.alt_from = 1 + live;
+                    io.rd0 = Rcur == R ? nullptr : Rcur;
+                    io.wr0 = Rcur == R ? R2 : nullptr;
+                    live += fresh;
+                    launch_pass(call, pd, k, R, 1, live + 1, &io);
+                    Rcur = Rcur == R ? R2 : R;
                     rpass = k + 1;
                 } else {
-                    launch_pass(call, pd, k, S, 2, live);
+                    io.alt_from = live;
+                    live += fresh;
+                    if (k + 1 == n_pass && fused_batch(call, hl, D >> kTileBits, nb, &io)) {
+                        io.F = F;
+                        io.partial = partial;
+                        io.write_state = 0;
+                        fused = true;
+                    }
+                    launch_pass(call, pd, k, S, 2, live, &io);
                 }
             }
             PairArgs pa = { F, hl.alt, row0, d_ord + a, d_coef + a, call.spec.shift };
-            rc = measure_states(call, S, cnt, 0, nb, partial, &pa, hl);
+            rc = measure_states(call, S, cnt, 0, nb, partial, &pa, hl, fused ? (int)(D >> kTileBits) : 0);
             if (rc) return rc;
         }
     }

@@ -292,9 +292,11 @@ __device__ __forceinline__ void prep_tables(const RegArgs& a, const Prog& pp, do
     // phase 0: phase tables from the explicit RZ / ZZ terms
     for (int i = tid; i < S * (N1 + N2); i += nthr) {
         const int s2 = i / (N1 + N2), k = i - s2 * (N1 + N2);
-        const int64_t e2 = e0 + s2;
+        // (a state slot behind the end of the list runs the last instance once more: its amplitudes must
+        // be finite, because the matrix-unit lane rotations multiply them by zero into their wave-mates)
+        const int64_t e2 = min(e0 + s2, a.E - 1);
         cplx ph = { 1.0, 0.0 };
-        if (e2 < a.E) {
+        {
             const int begin = k < N1 ? pp.d1[k].begin : pp.d2[k - N1].begin;
             const int count = k < N1 ? pp.d1[k].count : pp.d2[k - N1].count;
             if (count > 0) {
@@ -320,7 +322,7 @@ __device__ __forceinline__ void prep_tables(const RegArgs& a, const Prog& pp, do
             // the input-free entries: copies (same parity rule, other entries than the loop below)
             for (int i = tid; i < S * NU; i += nthr) {
                 const int s2 = i / NU, u = i - s2 * NU;
-                if (pp.uent[u].parity != parity || !pp.uent[u].input_free || e0 + s2 >= a.E) continue;
+                if (pp.uent[u].parity != parity || !pp.uent[u].input_free) continue;
                 const int d_before = pp.uent[u].d_before, d_after = pp.uent[u].d_after;
                 double2* tb = tabs + (size_t)s2 * tab_stride;
                 tb[u] = ctab[3 * u];
@@ -338,8 +340,8 @@ __device__ __forceinline__ void prep_tables(const RegArgs& a, const Prog& pp, do
         }
         for (int i = tid; i < S * ND; i += nthr) {
             const int s2 = i / ND, u = ctab ? pp.dep[i - s2 * ND] : i - s2 * ND;
-            const int64_t e2 = e0 + s2;
-            if (pp.uent[u].parity != parity || e2 >= a.E) continue;
+            const int64_t e2 = min(e0 + s2, a.E - 1);
+            if (pp.uent[u].parity != parity) continue;
             const int d_before = pp.uent[u].d_before, d_after = pp.uent[u].d_after;
             int b, sparam;
             double sval;
