@@ -222,6 +222,18 @@ struct XRec {                                 // one late gate: the amplitude ge
     int32_t p0, p1, pad;
     double2 v0, v1;
 };
+// one sweep as the pass kernel reads it (128 bytes, fetched a sweep ahead): the descriptor and the
+// rotations of a sweep without CNOTs
+struct SweepRec {
+    uint32_t pos_lo, pos_hi;                  // 4 bits per entry: tpos[0 .. kThreadBits), then gpos[0 .. 4)
+    int32_t flags;                            // bit s: rotation on group slot s; bit 4 + s: diag(1, b1) first; bit 8 + s: the
+                                              // two-shear form; bit 12 + s: the three-shear form; bit 16: operations from the records
+    int32_t run, next_run, x_begin, x_tab, x_count, nx_begin, nx_tab, op_begin, op_count;
+    int32_t rot[4];                           // the rotations' records (b1 is read there when it is needed)
+    double tu[4][2];                          // their shears
+};
+static_assert(sizeof(SweepRec) == 128, "SweepRec is fetched as two 64-byte scalar loads");
+
 struct TilePassArgs {
     int n;
     int tq[kTileBits];                        // tile position -> qubit (ascending)
@@ -229,7 +241,8 @@ struct TilePassArgs {
     int n_outer;
     int n_sweeps, first_run;                  // this pass
     int first_xb, first_xt;                   // x_begin, x_tab of first_run
-    int n_ops_total, n_runs_total, n_x_total; // row lengths of the per-instance tables
+    int n_ops_total, n_runs_total, n_x_total, n_sweeps_total; // row lengths of the per-instance tables
+    int sweep_off;                            // where the pass's sweeps start in a row
 #ifdef VQA_TILE_ABLATE
     int ablate;                               // timing experiments (libvqahip_abl.so): bit 0 no sweeps, 1 no LDS traffic in the sweeps, 2 no register operations, 3 no diagonal runs
 #endif
@@ -363,6 +376,37 @@ __global__ __launch_bounds__(kT) void k_prep_ops(const GroupOp* __restrict__ ops
     oprec[i] = r;
 }
 
+// the sweeps of every instance: swrec[ci * NS + k]
+__global__ __launch_bounds__(kT) void k_prep_sweeps(const SweepDesc* __restrict__ sweeps, int NS, int C,
+                                                    const OpRec* __restrict__ oprec, int NO, SweepRec* __restrict__ swrec) {
+    const int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;
+    if (i >= (int64_t)C * NS) return;
+    const int ci = (int)(i / NS), k = (int)(i - (int64_t)ci * NS);
+    const SweepDesc sd = sweeps[k];
+    SweepRec r;
+    uint64_t pos = 0;
+    for (int b = 0; b < kThreadBits; ++b) pos |= (uint64_t)sd.tpos[b] << (4 * b);
+    for (int j = 0; j < 4; ++j) pos |= (uint64_t)sd.gpos[j] << (4 * (kThreadBits + j));
+    r.pos_lo = (uint32_t)pos;
+    r.pos_hi = (uint32_t)(pos >> 32);
+    r.flags = sd.op_count > 0 ? 1 << 16 : 0;
+    r.run = sd.run; r.next_run = sd.next_run;
+    r.x_begin = sd.x_begin; r.x_tab = sd.x_tab; r.x_count = sd.x_count;
+    r.nx_begin = sd.nx_begin; r.nx_tab = sd.nx_tab;
+    r.op_begin = sd.op_begin; r.op_count = sd.op_count;
+    for (int j = 0; j < 4; ++j) {
+        r.rot[j] = sd.rot[j];
+        r.tu[j][0] = r.tu[j][1] = 0.0;
+        if (sd.rot[j] >= 0) {
+            const OpRec o = oprec[(int64_t)ci * NO + sd.rot[j]];
+            r.tu[j][0] = o.t;
+            r.tu[j][1] = o.u;
+            r.flags |= (1 << j) | ((o.code & 256) ? 16 << j : 0) | ((o.code & 512) ? 256 << j : 0) | ((o.code & 1024) ? 4096 << j : 0);
+        }
+    }
+    swrec[i] = r;
+}
+
 // the two 64-entry phase tables of every diagonal run of every instance, without the late gates:
 // pretab[(ci * NR + run) * 128 + e], e < 64: low six tile bits = e, e >= 64: high six = e - 64
 __global__ __launch_bounds__(128) void k_prep_tab(const TileGate* __restrict__ gates, const RunDesc* __restrict__ runs, int NR,
@@ -458,15 +502,15 @@ __device__ __forceinline__ void cswap_inplace(double& a, double& b, double m0, d
 
 // the rotation of a fused 2x2 on group slot J (see "Normal form"); pre: diag(1, b1) first
 template <int J>
-__device__ __forceinline__ void apply_rot(double2 (&a)[kTA], double t, double u, int code, c2 b1) {
-    if (code & 256) {
+__device__ __forceinline__ void apply_rot(double2 (&a)[kTA], double t, double u, bool pre, bool two, bool three, c2 b1) {
+    if (pre) {
 #pragma unroll
         for (int r = 0; r < kTA; ++r)
             if (r & (1 << J)) cmul_inplace(a[r].x, a[r].y, b1.x, b1.y);
     }
-    // the pairs of slot J, two at a time; the two forms are separate blocks (not an if / else)
+    // the pairs of slot J, two at a time; the two forms are separate blocks behind flags of their own (not an if / else)
     constexpr int lo = (1 << J) - 1;
-    if (code & 1024) {
+    if (three) {
 #pragma unroll
         for (int q = 0; q < kTA / 2; q += 2) {
             const int r0 = ((q & ~lo) << 1) | (q & lo), r1 = (((q + 1) & ~lo) << 1) | ((q + 1) & lo);
@@ -474,7 +518,7 @@ __device__ __forceinline__ void apply_rot(double2 (&a)[kTA], double t, double u,
                        a[r1 | (1 << J)].y, t, u);
         }
     }
-    if (code & 512) {
+    if (two) {
 #pragma unroll
         for (int q = 0; q < kTA / 2; q += 2) {
             const int r0 = ((q & ~lo) << 1) | (q & lo), r1 = (((q + 1) & ~lo) << 1) | ((q + 1) & lo);
@@ -512,17 +556,18 @@ __device__ __forceinline__ uint32_t tile_base(const TilePassArgs& a, uint32_t w)
 // set of registers around the loop over the operations)
 __device__ __forceinline__ void apply_op(double2 (&v)[kTA], const OpRec& r, int64_t base, int ib, const int (&off)[kTA]) {
     const c2 b1 = c2of(r.b1);
-    if (r.code & 1) apply_rot<0>(v, r.t, r.u, r.code, b1);
-    if (r.code & 2) apply_rot<1>(v, r.t, r.u, r.code, b1);
-    if (r.code & 4) apply_rot<2>(v, r.t, r.u, r.code, b1);
-    if (kGroup > 3 && (r.code & 8)) apply_rot<kGroup - 1>(v, r.t, r.u, r.code, b1);
+    const bool pre = (r.code & 256) != 0, two = (r.code & 512) != 0, three = (r.code & 1024) != 0;
+    if (r.code & 1) apply_rot<0>(v, r.t, r.u, pre, two, three, b1);
+    if (r.code & 2) apply_rot<1>(v, r.t, r.u, pre, two, three, b1);
+    if (r.code & 4) apply_rot<2>(v, r.t, r.u, pre, two, three, b1);
+    if (kGroup > 3 && (r.code & 8)) apply_rot<kGroup - 1>(v, r.t, r.u, pre, two, three, b1);
     if (r.code & 16) apply_cnot<0>(v, r.ctrl, base, ib, off);
     if (r.code & 32) apply_cnot<1>(v, r.ctrl, base, ib, off);
     if (r.code & 64) apply_cnot<2>(v, r.ctrl, base, ib, off);
     if (kGroup > 3 && (r.code & 128)) apply_cnot<kGroup - 1>(v, r.ctrl, base, ib, off);
 }
 
-constexpr int kFusedZ = 8;   // most Z-strings / marginal bins the last pass of a sweep measures itself
+constexpr int kFusedZ = 8;   // Z-strings / marginal bins the last pass of a sweep measures at a time (of up to kZBatch)
 
 // Where the states of a launch are read and written, and what the pass measures at its end.
 struct PassIO {
@@ -535,13 +580,13 @@ struct PassIO {
     const double2* F;
     double* partial;
     int nz, write_state;
-    uint32_t z[kFusedZ];
-    int32_t bin[kFusedZ];     // < 0: Z-string z (a sign); >= 0: the indicator of (index & z) == bin
+    uint32_t z[kZBatch];
+    int32_t bin[kZBatch];     // < 0: Z-string z (a sign); >= 0: the indicator of (index & z) == bin
 };
 
 // One workgroup runs the pass on one tile of one instance.
 template <int MEAS>
-__global__ __launch_bounds__(kTT, kTileWaves) void k_tile_pass(double2* __restrict__ st, const SweepDesc* __restrict__ sweeps,
+__global__ __launch_bounds__(kTT, kTileWaves) void k_tile_pass(double2* __restrict__ st, const SweepRec* __restrict__ swrec,
                                                    const OpRec* __restrict__ oprec, const double2* __restrict__ pretab,
                                                    const XRec* __restrict__ xrec, TilePassArgs a, PassIO io) {
     extern __shared__ double2 tile[];
@@ -554,6 +599,7 @@ __global__ __launch_bounds__(kTT, kTileWaves) void k_tile_pass(double2* __restri
     const OpRec* __restrict__ my_ops = oprec + (int64_t)ci * a.n_ops_total;
     const double2* __restrict__ my_tab = pretab + (int64_t)ci * a.n_runs_total * 128;
     const XRec* __restrict__ my_x = xrec + (int64_t)ci * a.n_x_total;
+    const SweepRec* __restrict__ my_sw = swrec + (int64_t)ci * a.n_sweeps_total + a.sweep_off;
     // local index l = k * kTT + tid (12 bits) -> global index; the low four bits are contiguous
     // (state indices fit 32 bits: at most 30 qubits)
     uint32_t g_tid = tid & ((1 << kTileLow) - 1);
@@ -600,22 +646,25 @@ __global__ __launch_bounds__(kTT, kTileWaves) void k_tile_pass(double2* __restri
         for (int k = 0; k < kTA; ++k) tile[tile_slot(k * kTT + tid)] = pv[k];
         if (a.first_run >= 0 && tid < 128) finish_table(ahead, a.first_xb, a.first_xt, dtab[0]);
         int cur = 0;   // which table the next diagonal run reads
+        SweepRec sw_next = my_sw[0];
         for (int si = 0; si < ((abl & 1) ? 0 : a.n_sweeps); ++si) {
             lds_barrier();   // the previous sweep's amplitudes (or the gathered tile) and the next table are in LDS
-            const SweepDesc sw = sweeps[si];
+            const SweepRec sw = sw_next;
+            sw_next = my_sw[min(si + 1, a.n_sweeps - 1)];   // on its way while this sweep runs
+            const uint64_t pos = ((uint64_t)sw.pos_hi << 32) | sw.pos_lo;
             const bool table_next = sw.run >= 0 && sw.next_run >= 0 && tid < 128;
             if (table_next) ahead = my_tab[sw.next_run * 128 + tid];
             const double2* dt = dtab[cur];
             // this thread's amplitudes: thread bits on tpos, register bits on gpos
             int ib = 0;
 #pragma unroll
-            for (int b = 0; b < kThreadBits; ++b) ib |= ((tid >> b) & 1) << sw.tpos[b];
+            for (int b = 0; b < kThreadBits; ++b) ib |= ((tid >> b) & 1) << (int)((pos >> (4 * b)) & 15);
             int off[kTA];
 #pragma unroll
             for (int r = 0; r < kTA; ++r) {
                 off[r] = 0;
 #pragma unroll
-                for (int j = 0; j < kGroup; ++j) off[r] |= ((r >> j) & 1) << sw.gpos[j];
+                for (int j = 0; j < kGroup; ++j) off[r] |= ((r >> j) & 1) << (int)((pos >> (4 * (kThreadBits + j))) & 15);
             }
             const int sb = tile_slot(ib);
             double2 v[kTA];
@@ -631,15 +680,21 @@ __global__ __launch_bounds__(kTT, kTileWaves) void k_tile_pass(double2* __restri
                     cur = nxt;
                 }
             }
-            if (sw.op_count == 0 && !(abl & 4)) {
+            if (!(abl & 4)) {
                 // at most one rotation per group slot and nothing else: they commute, and their
-                // records are fetched together
-                const OpRec r0 = my_ops[max(sw.rot[0], 0)], r1 = my_ops[max(sw.rot[1], 0)], r2 = my_ops[max(sw.rot[2], 0)],
-                            r3 = my_ops[max(sw.rot[kGroup - 1], 0)];
-                if (sw.rot[0] >= 0) apply_rot<0>(v, r0.t, r0.u, r0.code, c2of(r0.b1));
-                if (sw.rot[1] >= 0) apply_rot<1>(v, r1.t, r1.u, r1.code, c2of(r1.b1));
-                if (sw.rot[2] >= 0) apply_rot<2>(v, r2.t, r2.u, r2.code, c2of(r2.b1));
-                if (kGroup > 3 && sw.rot[kGroup - 1] >= 0) apply_rot<kGroup - 1>(v, r3.t, r3.u, r3.code, c2of(r3.b1));
+                // shears came with the sweep's record
+                const int f = sw.flags;
+#define VQA_ROT_SLOT(J)                                                                                         \
+                if (f & (1 << J)) {                                                                             \
+                    c2 b1 = { 1.0, 0.0 };                                                                       \
+                    if (f & (16 << J)) b1 = c2of(my_ops[sw.rot[J]].b1);                                         \
+                    apply_rot<J>(v, sw.tu[J][0], sw.tu[J][1], (f & (16 << J)) != 0, (f & (256 << J)) != 0,      \
+                                 (f & (4096 << J)) != 0, b1);                                                   \
+                }
+                VQA_ROT_SLOT(0) VQA_ROT_SLOT(1) VQA_ROT_SLOT(2)
+                constexpr int JL = kGroup - 1;
+                if (kGroup > 3) { VQA_ROT_SLOT(JL) }
+#undef VQA_ROT_SLOT
             }
             if (sw.run >= 0 && !(abl & 8)) {
 #pragma unroll
@@ -697,54 +752,61 @@ __global__ __launch_bounds__(kTT, kTileWaves) void k_tile_pass(double2* __restri
             // positions; an entry whose mask avoids them has one sign (or bin test) per thread and is
             // applied to the thread's plain sums.
             const uint32_t vary = g_k[kTA - 1];
-            double tot = 0.0, totx = 0.0, acc[kFusedZ], acx[kFusedZ];
-#pragma unroll
-            for (int t = 0; t < kFusedZ; ++t) acc[t] = acx[t] = 0.0;
-#pragma unroll
-            for (int k = 0; k < kTA; ++k) {
-                const double2 phi = tile[tile_slot(k * kTT + tid)], psi = pv[k];
-                const double pr = phi.x * phi.x + phi.y * phi.y, cr = psi.x * phi.x + psi.y * phi.y;
-                const uint32_t idx = base | g_tid | g_k[k];
-                tot += pr;
-                totx += cr;
-#pragma unroll
-                for (int t = 0; t < kFusedZ; ++t) {
-                    if (t < io.nz && (io.z[t] & vary)) {
-                        const bool on = io.bin[t] >= 0 ? (idx & io.z[t]) == (uint32_t)io.bin[t] : !(__popc(idx & io.z[t]) & 1);
-                        const double sg = io.bin[t] >= 0 ? (on ? 1.0 : 0.0) : (on ? 1.0 : -1.0);
-                        acc[t] += sg * pr;
-                        acx[t] += sg * cr;
-                    }
-                }
-            }
             __shared__ double red[2 * kFusedZ][kTT / 64];
             const uint32_t idx0 = base | g_tid;
+            for (int t0 = 0; t0 < io.nz; t0 += kFusedZ) {
+                double tot = 0.0, totx = 0.0, acc[kFusedZ], acx[kFusedZ];
 #pragma unroll
-            for (int t = 0; t < kFusedZ; ++t) {
-                if (t < io.nz) {
-                    if (!(io.z[t] & vary)) {
-                        const bool on = io.bin[t] >= 0 ? (idx0 & io.z[t]) == (uint32_t)io.bin[t] : !(__popc(idx0 & io.z[t]) & 1);
-                        const double sg = io.bin[t] >= 0 ? (on ? 1.0 : 0.0) : (on ? 1.0 : -1.0);
-                        acc[t] = sg * tot;
-                        acx[t] = sg * totx;
-                    }
-                    double va = acc[t], vx = acx[t];
-                    for (int o = 32; o > 0; o >>= 1) {
-                        va += __shfl_down(va, o, 64);
-                        vx += __shfl_down(vx, o, 64);
-                    }
-                    if ((tid & 63) == 0) {
-                        red[2 * t][tid >> 6] = va;
-                        red[2 * t + 1][tid >> 6] = vx;
+                for (int t = 0; t < kFusedZ; ++t) acc[t] = acx[t] = 0.0;
+#pragma unroll
+                for (int k = 0; k < kTA; ++k) {
+                    const double2 phi = tile[tile_slot(k * kTT + tid)], psi = pv[k];
+                    const double pr = phi.x * phi.x + phi.y * phi.y, cr = psi.x * phi.x + psi.y * phi.y;
+                    const uint32_t idx = idx0 | g_k[k];
+                    tot += pr;
+                    totx += cr;
+#pragma unroll
+                    for (int t = 0; t < kFusedZ; ++t) {
+                        const uint32_t z = io.z[min(t0 + t, kZBatch - 1)];
+                        const int bin = io.bin[min(t0 + t, kZBatch - 1)];
+                        if (t0 + t < io.nz && (z & vary)) {
+                            const bool on = bin >= 0 ? (idx & z) == (uint32_t)bin : !(__popc(idx & z) & 1);
+                            const double sg = bin >= 0 ? (on ? 1.0 : 0.0) : (on ? 1.0 : -1.0);
+                            acc[t] += sg * pr;
+                            acx[t] += sg * cr;
+                        }
                     }
                 }
-            }
-            __syncthreads();
-            if (tid < 2 * io.nz) {
-                double r = 0.0;
 #pragma unroll
-                for (int w = 0; w < kTT / 64; ++w) r += red[tid][w];
-                io.partial[(((int64_t)ci * gridDim.x + blockIdx.x) * kZBatch + (tid >> 1)) * 2 + (tid & 1)] = r;
+                for (int t = 0; t < kFusedZ; ++t) {
+                    if (t0 + t < io.nz) {
+                        const uint32_t z = io.z[min(t0 + t, kZBatch - 1)];
+                        const int bin = io.bin[min(t0 + t, kZBatch - 1)];
+                        if (!(z & vary)) {
+                            const bool on = bin >= 0 ? (idx0 & z) == (uint32_t)bin : !(__popc(idx0 & z) & 1);
+                            const double sg = bin >= 0 ? (on ? 1.0 : 0.0) : (on ? 1.0 : -1.0);
+                            acc[t] = sg * tot;
+                            acx[t] = sg * totx;
+                        }
+                        double va = acc[t], vx = acx[t];
+                        for (int o = 32; o > 0; o >>= 1) {
+                            va += __shfl_down(va, o, 64);
+                            vx += __shfl_down(vx, o, 64);
+                        }
+                        if ((tid & 63) == 0) {
+                            red[2 * t][tid >> 6] = va;
+                            red[2 * t + 1][tid >> 6] = vx;
+                        }
+                    }
+                }
+                __syncthreads();
+                if (tid < 2 * min(kFusedZ, io.nz - t0)) {
+                    double r = 0.0;
+#pragma unroll
+                    for (int w = 0; w < kTT / 64; ++w) r += red[tid][w];
+                    io.partial[(((int64_t)ci * gridDim.x + blockIdx.x) * kZBatch + t0 + (tid >> 1)) * 2 + (tid & 1)] = r;
+                }
+                __syncthreads();
             }
         }
     }
@@ -1002,20 +1064,43 @@ static TilePlan plan_tiles(int n, const std::vector<vqa_op>& ops, const std::vec
         }
         pg.swap(out);
     }
+    // The passes are cut from the END of the circuit backwards (the commutation rules are the same
+    // in both directions): each pass then holds as many of the latest units as it can, which puts a
+    // parameter's rotation into as late a pass as possible -- a parameter-shift sweep propagates one
+    // extra state per parameter from the pass of its rotation to the last one.
     std::vector<int> todo(pg.size());
-    for (size_t i = 0; i < pg.size(); ++i) todo[i] = (int)i;
+    for (size_t i = 0; i < pg.size(); ++i) todo[i] = (int)(pg.size() - 1 - i);
+    // the units of `todo` that a pass on the tile can run (at most cap of them), in order; the others in `rest`
+    auto take = [&](const int (&pos_of)[64], int cap, std::vector<TileGate>* taken, std::vector<int>* rest) {
+        uint64_t held = 0;
+        int n_taken = 0;
+        for (int gi : todo) {
+            const PG& op = pg[gi];
+            const uint64_t qs = ((uint64_t)1 << op.q0) | (op.q1 >= 0 ? (uint64_t)1 << op.q1 : 0);
+            const bool ok = !(held & qs) && (diag_kind(op.kind) || pos_of[op.q0] < 32) && n_taken < cap;
+            if (!ok) {
+                held |= qs;
+                if (rest) rest->push_back(gi);
+                continue;
+            }
+            ++n_taken;
+            if (taken) taken->push_back(TileGate{ op.kind, pos_of[op.q0], op.q1 >= 0 ? pos_of[op.q1] : -1, op.g });
+        }
+        return n_taken;
+    };
     while (!todo.empty()) {
-        // tile: the low qubits plus the first eight others that pending units need as targets
+        // tile: the low qubits plus the first others that pending units need as targets
+        const int n_free = kTileBits - kTileLow;
         std::vector<int> tile;
-        for (int q = 0; q < kTileLow; ++q) tile.push_back(q);
         for (int gi : todo) {
             const PG& op = pg[gi];
             if (diag_kind(op.kind) || op.q0 < kTileLow) continue;
             if (std::find(tile.begin(), tile.end(), op.q0) == tile.end()) tile.push_back(op.q0);
-            if ((int)tile.size() == kTileBits) break;
+            if ((int)tile.size() == n_free) break;
         }
-        for (int q = kTileLow; q < n && (int)tile.size() < kTileBits; ++q)
+        for (int q = kTileLow; q < n && (int)tile.size() < n_free; ++q)
             if (std::find(tile.begin(), tile.end(), q) == tile.end()) tile.push_back(q);
+        for (int q = 0; q < kTileLow; ++q) tile.push_back(q);
         std::sort(tile.begin(), tile.end());
         int pos_of[64];
         for (int q = 0; q < 64; ++q) pos_of[q] = 32 + q;                 // outer by default
@@ -1023,27 +1108,17 @@ static TilePlan plan_tiles(int n, const std::vector<vqa_op>& ops, const std::vec
         for (int cap = kGateBatch;; cap /= 2) {
             TilePlan::Pass pass;
             for (int p = 0; p < kTileBits; ++p) pass.tq[p] = tile[p];
-            uint64_t held = 0;
             std::vector<int> rest;
             std::vector<TileGate> taken;
-            for (int gi : todo) {
-                const PG& op = pg[gi];
-                const uint64_t qs = ((uint64_t)1 << op.q0) | (op.q1 >= 0 ? (uint64_t)1 << op.q1 : 0);
-                const bool ok = !(held & qs) && (diag_kind(op.kind) || pos_of[op.q0] < 32) &&
-                                (int)taken.size() < cap;
-                if (!ok) {
-                    held |= qs;
-                    rest.push_back(gi);
-                    continue;
-                }
-                taken.push_back(TileGate{ op.kind, pos_of[op.q0], op.q1 >= 0 ? pos_of[op.q1] : -1, op.g });
-            }
+            take(pos_of, cap, &taken, &rest);
+            std::reverse(taken.begin(), taken.end());   // back into circuit order
             if (!group_sweeps(pass, taken, runs) && cap > 1) continue;
             todo.swap(rest);
             plan.passes.push_back(std::move(pass));
             break;
         }
     }
+    std::reverse(plan.passes.begin(), plan.passes.end());
     plan.pass_of_gate.assign(ops.size(), -1);
     for (size_t k = 0; k < plan.passes.size(); ++k) {
         const auto& p = plan.passes[k];
@@ -1308,24 +1383,34 @@ __global__ __launch_bounds__(kT) void k_zpart2(const double2* f, const double2* 
     const uint32_t vary = (uint32_t)((L - 1) & ~(int64_t)(kT - 1));
     const uint32_t k0 = (uint32_t)(blk * L + threadIdx.x);
     double tot = 0.0, totx = 0.0;
-    for (int64_t k = blk * L + threadIdx.x; k < (blk + 1) * L; k += kT) {
-        const double2 v = s[k], u = f[k];
-        const double pr = v.x * v.x + v.y * v.y;
-        const double cr = u.x * v.x + u.y * v.y;
-        const uint32_t k32 = (uint32_t)k;
-        tot += pr;
-        totx += cr;
+    // four amplitudes of each state per round, their loads in flight together (a slice holds a multiple of 4 kT)
+    for (int64_t kb = blk * L + threadIdx.x; kb < (blk + 1) * L; kb += 4 * kT) {
+        double2 v4[4], u4[4];
 #pragma unroll
-        for (int t = 0; t < NZ; ++t) {
-            if (t < zb.nz && ((uint32_t)zb.z[t] & vary)) {
-                if (zb.bin[t] >= 0) {
-                    const bool in = (k32 & (uint32_t)zb.z[t]) == (uint32_t)zb.bin[t];
-                    acc[t] += in ? pr : 0.0;
-                    acx[t] += in ? cr : 0.0;
-                } else {
-                    const bool neg = __popc(k32 & (uint32_t)zb.z[t]) & 1;
-                    acc[t] += neg ? -pr : pr;
-                    acx[t] += neg ? -cr : cr;
+        for (int j = 0; j < 4; ++j) {
+            v4[j] = s[kb + j * kT];
+            u4[j] = f[kb + j * kT];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double2 v = v4[j], u = u4[j];
+            const double pr = v.x * v.x + v.y * v.y;
+            const double cr = u.x * v.x + u.y * v.y;
+            const uint32_t k32 = (uint32_t)(kb + j * kT);
+            tot += pr;
+            totx += cr;
+#pragma unroll
+            for (int t = 0; t < NZ; ++t) {
+                if (t < zb.nz && ((uint32_t)zb.z[t] & vary)) {
+                    if (zb.bin[t] >= 0) {
+                        const bool in = (k32 & (uint32_t)zb.z[t]) == (uint32_t)zb.bin[t];
+                        acc[t] += in ? pr : 0.0;
+                        acx[t] += in ? cr : 0.0;
+                    } else {
+                        const bool neg = __popc(k32 & (uint32_t)zb.z[t]) & 1;
+                        acc[t] += neg ? -pr : pr;
+                        acx[t] += neg ? -cr : cr;
+                    }
                 }
             }
         }
@@ -1544,7 +1629,7 @@ PlanImage plan_image(const TilePlan& p, void* buf) {
 struct PlanDev {
     const TilePlan* plan = nullptr;
     void* buf = nullptr;       // plan_image_bytes(*plan)
-    char* inst = nullptr;      // inst_bytes(instances): mats | oprec | pretab | xrec, each [instances][row]
+    char* inst = nullptr;      // inst_bytes(instances): mats | oprec | pretab | xrec | swrec, each [instances][row]
     int64_t cap = 0;           // instances the tables are carved for
     size_t n_mats() const { return std::max<size_t>(plan->all_mats.size(), 1); }
     size_t n_ops() const { return std::max<size_t>(plan->all_ops.size(), 1); }
@@ -1555,12 +1640,17 @@ struct PlanDev {
     size_t ops_bytes(int64_t C) const { return pad256((size_t)C * n_ops() * sizeof(OpRec)); }
     size_t tab_bytes(int64_t C) const { return pad256((size_t)C * n_runs() * 128 * sizeof(double2)); }
     size_t x_bytes(int64_t C) const { return pad256((size_t)C * n_x() * sizeof(XRec)); }
-    size_t inst_bytes(int64_t C) const { return mats_bytes(C) + ops_bytes(C) + tab_bytes(C) + x_bytes(C); }
+    size_t n_sw() const { return std::max<size_t>(plan->all_sweeps.size(), 1); }
+    size_t sw_bytes(int64_t C) const { return pad256((size_t)C * n_sw() * sizeof(SweepRec)); }
+    size_t inst_bytes(int64_t C) const { return mats_bytes(C) + ops_bytes(C) + tab_bytes(C) + x_bytes(C) + sw_bytes(C); }
     void carve(char* p, int64_t C) { inst = p; cap = C; }
     double2* mats(int64_t slot) const { return (double2*)inst + slot * n_mats() * 4; }
     OpRec* oprec(int64_t slot) const { return (OpRec*)(inst + mats_bytes(cap)) + slot * n_ops(); }
     double2* pretab(int64_t slot) const { return (double2*)(inst + mats_bytes(cap) + ops_bytes(cap)) + slot * n_runs() * 128; }
     XRec* xrec(int64_t slot) const { return (XRec*)(inst + mats_bytes(cap) + ops_bytes(cap) + tab_bytes(cap)) + slot * n_x(); }
+    SweepRec* swrec(int64_t slot) const {
+        return (SweepRec*)(inst + mats_bytes(cap) + ops_bytes(cap) + tab_bytes(cap) + x_bytes(cap)) + slot * n_sw();
+    }
 };
 
 // copies the plan's tables (a plan lives as long as its circuit, so the asynchronous
@@ -1605,6 +1695,10 @@ void launch_mats(const EvalCall& call, const PlanDev& pd, const double2* tab, in
     if (NX > 0)
         hipLaunchKernelGGL(k_prep_x, grid((int64_t)C * NX), dim3(kT), 0, call.stream, im.xgates, NX, C, tab, tab_stride,
                            pd.xrec(slot0));
+    const int NS = (int)plan.all_sweeps.size();
+    if (NS > 0)
+        hipLaunchKernelGGL(k_prep_sweeps, grid((int64_t)C * NS), dim3(kT), 0, call.stream, im.sweeps, NS, C, pd.oprec(slot0),
+                           (int)pd.n_ops(), pd.swrec(slot0));
 }
 
 thread_local int64_t t_state_passes = 0;   // states x passes launched by this thread (VQA_PLAN_DEBUG report)
@@ -1617,7 +1711,6 @@ void launch_pass(const EvalCall& call, const PlanDev& pd, size_t k, double2* st,
     if (p.sweeps.empty() || C <= 0) return;
     t_state_passes += C;
     const int n = call.c->n_qubits;
-    const PlanImage im = plan_image(plan, pd.buf);
     TilePassArgs a;
     a.n = n;
     a.n_outer = 0;
@@ -1634,6 +1727,8 @@ void launch_pass(const EvalCall& call, const PlanDev& pd, size_t k, double2* st,
     a.n_ops_total = (int)pd.n_ops();
     a.n_runs_total = (int)pd.n_runs();
     a.n_x_total = (int)pd.n_x();
+    a.n_sweeps_total = (int)pd.n_sw();
+    a.sweep_off = (int)plan.soff[k];
     const int64_t n_tiles = ((int64_t)1 << n) >> kTileBits;
 #ifdef VQA_TILE_ABLATE
     a.ablate = getenv("VQA_TILE_ABLATE") ? atoi(getenv("VQA_TILE_ABLATE")) : 0;
@@ -1648,10 +1743,10 @@ void launch_pass(const EvalCall& call, const PlanDev& pd, size_t k, double2* st,
     const dim3 grid((unsigned)n_tiles, C);
     if (pio.nz > 0)
         hipLaunchKernelGGL(k_tile_pass<1>, grid, dim3(kTT), kTileAmps * sizeof(double2), call.stream, st,
-                           im.sweeps + plan.soff[k], pd.oprec(slot0), pd.pretab(slot0), pd.xrec(slot0), a, pio);
+                           pd.swrec(slot0), pd.oprec(slot0), pd.pretab(slot0), pd.xrec(slot0), a, pio);
     else
         hipLaunchKernelGGL(k_tile_pass<0>, grid, dim3(kTT), kTileAmps * sizeof(double2), call.stream, st,
-                           im.sweeps + plan.soff[k], pd.oprec(slot0), pd.pretab(slot0), pd.xrec(slot0), a, pio);
+                           pd.swrec(slot0), pd.oprec(slot0), pd.pretab(slot0), pd.xrec(slot0), a, pio);
 }
 
 void launch_all_passes(const EvalCall& call, const PlanDev& pd, double2* st, int slot0, int C) {
@@ -1711,11 +1806,17 @@ struct HLayer {
     double2* alt = nullptr;
 };
 
-// fused_nb > 0 (pairs, see fused_batch): the last pass has written the partial sums of the one batch
-// itself, fused_nb of them per state.
+// What the tiled passes of a sweep measure themselves (pairs only; see fuse_plan): the one batch of
+// Z-strings (with the marginal bins) at the end of the circuit's last pass, the one batch of pure-X
+// strings at the end of the Hadamard layer's last pass.  Their partial sums come one per tile.
+struct FuseInfo {
+    bool main = false, h = false;
+    bool main_write = true;   // the circuit's last pass still writes the final states (something else reads them)
+    int n_tiles = 0;
+};
+
 int measure_states(const EvalCall& call, double2* st, int C, int64_t e0, int nb, double* partial,
-                   const PairArgs* pair, const HLayer& hl, int fused_nb = 0) {
-    if (fused_nb > 0) nb = fused_nb;
+                   const PairArgs* pair, const HLayer& hl, const FuseInfo* fu = nullptr) {
     const int n = call.c->n_qubits;
     const int n_obs = call.obs.n_obs;
     if (n_obs > 0) {
@@ -1731,7 +1832,9 @@ int measure_states(const EvalCall& call, double2* st, int C, int64_t e0, int nb,
     // the last Z-strings (entries nzs .. nz - 1 of the batch).
     const int M = call.n_marg_bits > 0 ? 1 << call.n_marg_bits : 0;
     bool marg_done = M == 0;
-    auto zflush = [&](ZBatch& zb, const double2* states, const double2* f, bool last) {
+    auto zflush = [&](ZBatch& zb, const double2* states, const double2* f, bool last, bool fused = false) {
+        const int nb_unfused = nb;
+        const int nb = fused ? fu->n_tiles : nb_unfused;
         const int nzs = zb.nz;
         int nbins = 0;
         if (last && !marg_done && nzs + M <= kZBatch) {
@@ -1747,7 +1850,7 @@ int measure_states(const EvalCall& call, double2* st, int C, int64_t e0, int nb,
         }
         if (zb.nz == 0) return;
         if (pair) {
-            if (fused_nb > 0) {}
+            if (fused) {}
             else if (zb.nz <= 8) hipLaunchKernelGGL(k_zpart2<8>, dim3(C, nb), dim3(kT), 0, call.stream, f, states, n, zb, partial);
             else hipLaunchKernelGGL(k_zpart2<kZBatch>, dim3(C, nb), dim3(kT), 0, call.stream, f, states, n, zb, partial);
             if (nzs)
@@ -1777,10 +1880,10 @@ int measure_states(const EvalCall& call, double2* st, int C, int64_t e0, int nb,
             zb.coef[zb.nz] = call.obs.coef[t];
             zb.col[zb.nz] = o;
             zb.bin[zb.nz] = -1;
-            if (++zb.nz == kZBatch) zflush(zb, st, pair ? pair->f : nullptr, false);
+            if (++zb.nz == kZBatch && !(fu && fu->main)) zflush(zb, st, pair ? pair->f : nullptr, false);
         }
     }
-    zflush(zb, st, pair ? pair->f : nullptr, true);
+    zflush(zb, st, pair ? pair->f : nullptr, true, fu && fu->main);
     // X/Y strings one at a time, except the pure-X ones when the Hadamard layer is in use
     for (int o = 0; o < n_obs; ++o) {
         for (int t = call.obs.off[o]; t < call.obs.off[o + 1]; ++t) {
@@ -1830,8 +1933,26 @@ int measure_states(const EvalCall& call, double2* st, int C, int64_t e0, int nb,
             hipLaunchKernelGGL(k_spawn, dim3((unsigned)((D + kT - 1) / kT)), dim3(kT), 0, call.stream, hl.alt, st, D, 1);
             hs = hl.alt;
         }
+        const bool hf = fu && fu->h;
         launch_mats(call, hl.pd, nullptr, 0, 0, C);
-        launch_all_passes(call, hl.pd, hs, 0, C);
+        if (hf) {
+            // the layer's last pass measures the strings and leaves the states unwritten
+            const size_t np = hl.pd.plan->passes.size();
+            for (size_t k = 0; k + 1 < np; ++k) launch_pass(call, hl.pd, k, hs, 0, C);
+            PassIO io;
+            memset(&io, 0, sizeof(io));
+            io.alt_from = 1 << 30;
+            io.F = pair->fh;
+            io.partial = partial;
+            for (int t = 0; t < call.obs.n_terms; ++t) {
+                if (call.obs.x[t] == 0 || call.obs.z[t] != 0) continue;
+                io.z[io.nz] = (uint32_t)call.obs.x[t];
+                io.bin[io.nz++] = -1;
+            }
+            launch_pass(call, hl.pd, np - 1, hs, 0, C, &io);
+        } else {
+            launch_all_passes(call, hl.pd, hs, 0, C);
+        }
         zb.nz = 0;
         for (int o = 0; o < n_obs; ++o) {
             for (int t = call.obs.off[o]; t < call.obs.off[o + 1]; ++t) {
@@ -1840,36 +1961,47 @@ int measure_states(const EvalCall& call, double2* st, int C, int64_t e0, int nb,
                 zb.coef[zb.nz] = call.obs.coef[t];
                 zb.col[zb.nz] = o;
                 zb.bin[zb.nz] = -1;
-                if (++zb.nz == kZBatch) zflush(zb, hs, pair ? pair->fh : nullptr, false);
+                if (++zb.nz == kZBatch && !hf) zflush(zb, hs, pair ? pair->fh : nullptr, false);
             }
         }
-        zflush(zb, hs, pair ? pair->fh : nullptr, false);
+        zflush(zb, hs, pair ? pair->fh : nullptr, false, hf);
     }
     VQA_HIP(hipGetLastError());
     return VQA_OK;
 }
 
-// The one batch of Z-strings and marginal bins of a call, in the order measure_states() puts them
-// together, when that is all the call measures and the last pass of a sweep can take it: false otherwise.
-bool fused_batch(const EvalCall& call, const HLayer& hl, int64_t n_tiles, int nb, PassIO* io) {
-    if (hl.pd.plan || n_tiles > nb || getenv("VQA_NO_FUSED_MEASURE")) return false;
+// What the passes of a sweep can measure themselves.  io (filled when fu->main): the one batch of
+// Z-strings and marginal bins, in the order measure_states() puts them together.
+void fuse_plan(const EvalCall& call, const HLayer& hl, int64_t n_tiles, FuseInfo* fu, PassIO* io) {
+    *fu = FuseInfo();
+    fu->n_tiles = (int)n_tiles;
+    if (getenv("VQA_NO_FUSED_MEASURE") || n_tiles > (1 << 18)) return;
     const int M = call.n_marg_bits > 0 ? 1 << call.n_marg_bits : 0;
-    int nz = 0;
+    int nz = 0, nx = 0, nmixed = 0;
     for (int t = 0; t < call.obs.n_terms; ++t) {
-        if (call.obs.x[t] != 0) return false;
-        if (nz < kFusedZ) {
-            io->z[nz] = (uint32_t)call.obs.z[t];
-            io->bin[nz] = -1;
+        if (call.obs.x[t] == 0) {
+            if (nz < kZBatch) {
+                io->z[nz] = (uint32_t)call.obs.z[t];
+                io->bin[nz] = -1;
+            }
+            ++nz;
+        } else if (hl.pd.plan && call.obs.z[t] == 0) {
+            ++nx;
+        } else {
+            ++nmixed;
         }
-        ++nz;
     }
-    if (nz + M > kFusedZ || nz + M == 0) return false;
-    for (int m = 0; m < M; ++m) {
-        io->z[nz + m] = (uint32_t)(M - 1);
-        io->bin[nz + m] = m;
+    // (more than one round of kFusedZ entries costs the pass more than the separate reduction kernels take)
+    if (nz + M <= kFusedZ && nz + M > 0) {
+        for (int m = 0; m < M; ++m) {
+            io->z[nz + m] = (uint32_t)(M - 1);
+            io->bin[nz + m] = m;
+        }
+        io->nz = nz + M;
+        fu->main = true;
+        fu->main_write = hl.pd.plan || nmixed > 0;
     }
-    io->nz = nz + M;
-    return true;
+    fu->h = hl.pd.plan && nx > 0 && nx <= kFusedZ;
 }
 
 }  // namespace
@@ -2031,7 +2163,12 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
     Carver cv;
     const size_t o_st = cv.add((size_t)(C + 4) * D * sizeof(double2));
     const size_t o_tab = cv.add((size_t)(C + 2) * n_ops * sizeof(double2));
-    const size_t o_part = cv.add((size_t)C * nb * kZBatch * 2 * sizeof(double));
+    FuseInfo fu;
+    PassIO fio;
+    memset(&fio, 0, sizeof(fio));
+    fuse_plan(call, hl, D >> kTileBits, &fu, &fio);
+    const size_t nb_part = std::max<size_t>(nb, (fu.main || fu.h) ? (size_t)fu.n_tiles : 0);
+    const size_t o_part = cv.add((size_t)C * nb_part * kZBatch * 2 * sizeof(double));
     const size_t o_gate = cv.add(pd.image_bytes());
     const size_t o_inst = cv.add(pd.inst_bytes(C + 2));
     const size_t o_ord = cv.add((size_t)std::max(m, 1) * sizeof(int32_t));
@@ -2116,7 +2253,6 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
             launch_mats(call, pd, tab, h.n_ops, 0, cnt + 2);
             for (; rpass < k0; ++rpass) launch_pass(call, pd, rpass, Rcur, 1, 1);
             int live = 0;
-            bool fused = false;
             for (size_t k = k0; k < n_pass; ++k) {
                 // the states whose rotation sits in this pass branch off the running state: they read it
                 int fresh = 0;
@@ -2136,17 +2272,19 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
                 } else {
                     io.alt_from = live;
                     live += fresh;
-                    if (k + 1 == n_pass && fused_batch(call, hl, D >> kTileBits, nb, &io)) {
+                    if (k + 1 == n_pass && fu.main) {
+                        memcpy(io.z, fio.z, sizeof(io.z));
+                        memcpy(io.bin, fio.bin, sizeof(io.bin));
+                        io.nz = fio.nz;
                         io.F = F;
                         io.partial = partial;
-                        io.write_state = 0;
-                        fused = true;
+                        io.write_state = fu.main_write ? 1 : 0;
                     }
                     launch_pass(call, pd, k, S, 2, live, &io);
                 }
             }
             PairArgs pa = { F, hl.alt, row0, d_ord + a, d_coef + a, call.spec.shift };
-            rc = measure_states(call, S, cnt, 0, nb, partial, &pa, hl, fused ? (int)(D >> kTileBits) : 0);
+            rc = measure_states(call, S, cnt, 0, nb, partial, &pa, hl, &fu);
             if (rc) return rc;
         }
     }
