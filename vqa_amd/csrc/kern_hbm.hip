@@ -567,7 +567,29 @@ __device__ __forceinline__ void apply_op(double2 (&v)[kTA], const OpRec& r, int6
     if (kGroup > 3 && (r.code & 128)) apply_cnot<kGroup - 1>(v, r.ctrl, base, ib, off);
 }
 
-constexpr int kFusedZ = 8;   // Z-strings / marginal bins the last pass of a sweep measures at a time (of up to kZBatch)
+
+// Sum of v over the 64 lanes of a wave (every lane gets it): DPP inside the rows of 16 lanes, then
+// the four row sums through scalar registers.
+template <int CTRL>
+__device__ __forceinline__ double row_step(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+    return v + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum(double v) {
+    v = row_step<0xB1>(v);    // quad_perm [1,0,3,2]
+    v = row_step<0x4E>(v);    // quad_perm [2,3,0,1]
+    v = row_step<0x141>(v);   // row_half_mirror
+    v = row_step<0x140>(v);   // row_mirror
+    double s = 0.0;
+#pragma unroll
+    for (int row = 0; row < 4; ++row) {
+        const int lo = __builtin_amdgcn_readlane(__double2loint(v), row * 16);
+        const int hi = __builtin_amdgcn_readlane(__double2hiint(v), row * 16);
+        s += __hiloint2double(hi, lo);
+    }
+    return s;
+}
 
 // Where the states of a launch are read and written, and what the pass measures at its end.
 struct PassIO {
@@ -580,6 +602,7 @@ struct PassIO {
     const double2* F;
     double* partial;
     int nz, write_state;
+    int state_first, n_states;   // set by launch_pass: the order of the workgroups
     uint32_t z[kZBatch];
     int32_t bin[kZBatch];     // < 0: Z-string z (a sign); >= 0: the indicator of (index & z) == bin
 };
@@ -592,7 +615,11 @@ __global__ __launch_bounds__(kTT, kTileWaves) void k_tile_pass(double2* __restri
     extern __shared__ double2 tile[];
     __shared__ double2 dtab[2][128];   // the phase tables of the current diagonal run and of the next one
     const int tid = threadIdx.x;
-    const int ci = blockIdx.y;
+    // workgroup number -> (tile, state); states first when they read a common state (its tile then
+    // comes from HBM once for all of them)
+    const uint32_t n_tiles = 1u << (a.n - kTileBits);
+    const int ci = io.state_first ? (int)(blockIdx.x % (uint32_t)io.n_states) : (int)(blockIdx.x >> (a.n - kTileBits));
+    const uint32_t tile_no = io.state_first ? blockIdx.x / (uint32_t)io.n_states : blockIdx.x & (n_tiles - 1);
     double2* own = st + ((int64_t)ci << a.n);
     const double2* s = ci >= io.alt_from ? io.alt_src : (ci == 0 && io.rd0) ? io.rd0 : own;
     double2* sout = (ci == 0 && io.wr0) ? io.wr0 : own;
@@ -612,7 +639,7 @@ __global__ __launch_bounds__(kTT, kTileWaves) void k_tile_pass(double2* __restri
 #pragma unroll
         for (int j = kThreadBits; j < kTileBits; ++j) g_k[k] |= (uint32_t)((k >> (j - kThreadBits)) & 1) << a.tq[j];
     }
-    const uint32_t base = tile_base(a, blockIdx.x);
+    const uint32_t base = tile_base(a, tile_no);
     double2 pv[kTA];
 #pragma unroll
     for (int k = 0; k < kTA; ++k) pv[k] = s[base | g_tid | g_k[k]];
@@ -748,65 +775,67 @@ __global__ __launch_bounds__(kTT, kTileWaves) void k_tile_pass(double2* __restri
             for (int k = 0; k < kTA; ++k) sout[base | g_tid | g_k[k]] = tile[tile_slot(k * kTT + tid)];
         }
         if (MEAS) {
-            // The index bits that differ between a thread's amplitudes are the four highest tile
-            // positions; an entry whose mask avoids them has one sign (or bin test) per thread and is
-            // applied to the thread's plain sums.
-            const uint32_t vary = g_k[kTA - 1];
-            __shared__ double red[2 * kFusedZ][kTT / 64];
-            const uint32_t idx0 = base | g_tid;
-            for (int t0 = 0; t0 < io.nz; t0 += kFusedZ) {
-                double tot = 0.0, totx = 0.0, acc[kFusedZ], acx[kFusedZ];
+            // The index bits that differ between a thread's amplitudes are the kGroup highest tile
+            // positions.  A Walsh-Hadamard transform over them gives, per thread, the sums of |phi|^2 and of
+            // Re(conj(psi) phi) under every sign pattern of those bits; they are parked in LDS (the tile is
+            // not needed any more), and an entry is then the sum over the threads of its pattern's value
+            // times the sign (or bin test) of the thread's own index bits.  A bin's mask must avoid the
+            // varying bits (the low qubits of a marginal always do: they are thread bits).
+            double wp[kTA], wc[kTA];
 #pragma unroll
-                for (int t = 0; t < kFusedZ; ++t) acc[t] = acx[t] = 0.0;
+            for (int k = 0; k < kTA; ++k) {
+                const double2 phi = tile[tile_slot(k * kTT + tid)], psi = pv[k];
+                wp[k] = phi.x * phi.x + phi.y * phi.y;
+                wc[k] = psi.x * phi.x + psi.y * phi.y;
+            }
+#pragma unroll
+            for (int h = 1; h < kTA; h <<= 1) {
 #pragma unroll
                 for (int k = 0; k < kTA; ++k) {
-                    const double2 phi = tile[tile_slot(k * kTT + tid)], psi = pv[k];
-                    const double pr = phi.x * phi.x + phi.y * phi.y, cr = psi.x * phi.x + psi.y * phi.y;
-                    const uint32_t idx = idx0 | g_k[k];
-                    tot += pr;
-                    totx += cr;
-#pragma unroll
-                    for (int t = 0; t < kFusedZ; ++t) {
-                        const uint32_t z = io.z[min(t0 + t, kZBatch - 1)];
-                        const int bin = io.bin[min(t0 + t, kZBatch - 1)];
-                        if (t0 + t < io.nz && (z & vary)) {
-                            const bool on = bin >= 0 ? (idx & z) == (uint32_t)bin : !(__popc(idx & z) & 1);
-                            const double sg = bin >= 0 ? (on ? 1.0 : 0.0) : (on ? 1.0 : -1.0);
-                            acc[t] += sg * pr;
-                            acx[t] += sg * cr;
-                        }
-                    }
+                    if (k & h) continue;
+                    const double a0 = wp[k], a1 = wp[k | h], c0 = wc[k], c1 = wc[k | h];
+                    wp[k] = a0 + a1; wp[k | h] = a0 - a1;
+                    wc[k] = c0 + c1; wc[k | h] = c0 - c1;
                 }
+            }
+            __syncthreads();   // everybody has read the tile
+            double* wl = reinterpret_cast<double*>(tile);   // [pattern][quantity][thread]
 #pragma unroll
-                for (int t = 0; t < kFusedZ; ++t) {
-                    if (t0 + t < io.nz) {
-                        const uint32_t z = io.z[min(t0 + t, kZBatch - 1)];
-                        const int bin = io.bin[min(t0 + t, kZBatch - 1)];
-                        if (!(z & vary)) {
-                            const bool on = bin >= 0 ? (idx0 & z) == (uint32_t)bin : !(__popc(idx0 & z) & 1);
-                            const double sg = bin >= 0 ? (on ? 1.0 : 0.0) : (on ? 1.0 : -1.0);
-                            acc[t] = sg * tot;
-                            acx[t] = sg * totx;
-                        }
-                        double va = acc[t], vx = acx[t];
-                        for (int o = 32; o > 0; o >>= 1) {
-                            va += __shfl_down(va, o, 64);
-                            vx += __shfl_down(vx, o, 64);
-                        }
-                        if ((tid & 63) == 0) {
-                            red[2 * t][tid >> 6] = va;
-                            red[2 * t + 1][tid >> 6] = vx;
-                        }
-                    }
-                }
-                __syncthreads();
-                if (tid < 2 * min(kFusedZ, io.nz - t0)) {
-                    double r = 0.0;
+            for (int k = 0; k < kTA; ++k) {
+                wl[(2 * k) * kTT + tid] = wp[k];
+                wl[(2 * k + 1) * kTT + tid] = wc[k];
+            }
+            __syncthreads();
+            const int wave = tid >> 6, lane = tid & 63;
+            // the own index bits of the threads lane, lane + 64, ...
+            uint32_t g_lane = lane & ((1 << kTileLow) - 1);
 #pragma unroll
-                    for (int w = 0; w < kTT / 64; ++w) r += red[tid][w];
-                    io.partial[(((int64_t)ci * gridDim.x + blockIdx.x) * kZBatch + t0 + (tid >> 1)) * 2 + (tid & 1)] = r;
+            for (int j = kTileLow; j < 6; ++j) g_lane |= (uint32_t)((lane >> j) & 1) << a.tq[j];
+            for (int t = wave; t < io.nz; t += kTT / 64) {
+                const uint32_t z = io.z[t];
+                const int bin = io.bin[t];
+                int pat = 0;
+#pragma unroll
+                for (int j = 0; j < kGroup; ++j) pat |= (int)((z >> a.tq[kThreadBits + j]) & 1) << j;
+                if (bin >= 0) pat = 0;
+                double va = 0.0, vx = 0.0;
+#pragma unroll
+                for (int w = 0; w < kTT / 64; ++w) {
+                    uint32_t idx = base | g_lane;
+#pragma unroll
+                    for (int j = 6; j < kThreadBits; ++j) idx |= (uint32_t)((w >> (j - 6)) & 1) << a.tq[j];
+                    const bool on = bin >= 0 ? (idx & z) == (uint32_t)bin : !(__popc(idx & z) & 1);
+                    const double sg = bin >= 0 ? (on ? 1.0 : 0.0) : (on ? 1.0 : -1.0);
+                    va += sg * wl[(2 * pat) * kTT + w * 64 + lane];
+                    vx += sg * wl[(2 * pat + 1) * kTT + w * 64 + lane];
                 }
-                __syncthreads();
+                va = wave_sum(va);
+                vx = wave_sum(vx);
+                if (lane == 0) {
+                    double* out = &io.partial[(((int64_t)ci * n_tiles + tile_no) * kZBatch + t) * 2];
+                    out[0] = va;
+                    out[1] = vx;
+                }
             }
         }
     }
@@ -1383,34 +1412,24 @@ __global__ __launch_bounds__(kT) void k_zpart2(const double2* f, const double2* 
     const uint32_t vary = (uint32_t)((L - 1) & ~(int64_t)(kT - 1));
     const uint32_t k0 = (uint32_t)(blk * L + threadIdx.x);
     double tot = 0.0, totx = 0.0;
-    // four amplitudes of each state per round, their loads in flight together (a slice holds a multiple of 4 kT)
-    for (int64_t kb = blk * L + threadIdx.x; kb < (blk + 1) * L; kb += 4 * kT) {
-        double2 v4[4], u4[4];
+    for (int64_t k = blk * L + threadIdx.x; k < (blk + 1) * L; k += kT) {
+        const double2 v = s[k], u = f[k];
+        const double pr = v.x * v.x + v.y * v.y;
+        const double cr = u.x * v.x + u.y * v.y;
+        const uint32_t k32 = (uint32_t)k;
+        tot += pr;
+        totx += cr;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            v4[j] = s[kb + j * kT];
-            u4[j] = f[kb + j * kT];
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const double2 v = v4[j], u = u4[j];
-            const double pr = v.x * v.x + v.y * v.y;
-            const double cr = u.x * v.x + u.y * v.y;
-            const uint32_t k32 = (uint32_t)(kb + j * kT);
-            tot += pr;
-            totx += cr;
-#pragma unroll
-            for (int t = 0; t < NZ; ++t) {
-                if (t < zb.nz && ((uint32_t)zb.z[t] & vary)) {
-                    if (zb.bin[t] >= 0) {
-                        const bool in = (k32 & (uint32_t)zb.z[t]) == (uint32_t)zb.bin[t];
-                        acc[t] += in ? pr : 0.0;
-                        acx[t] += in ? cr : 0.0;
-                    } else {
-                        const bool neg = __popc(k32 & (uint32_t)zb.z[t]) & 1;
-                        acc[t] += neg ? -pr : pr;
-                        acx[t] += neg ? -cr : cr;
-                    }
+        for (int t = 0; t < NZ; ++t) {
+            if (t < zb.nz && ((uint32_t)zb.z[t] & vary)) {
+                if (zb.bin[t] >= 0) {
+                    const bool in = (k32 & (uint32_t)zb.z[t]) == (uint32_t)zb.bin[t];
+                    acc[t] += in ? pr : 0.0;
+                    acx[t] += in ? cr : 0.0;
+                } else {
+                    const bool neg = __popc(k32 & (uint32_t)zb.z[t]) & 1;
+                    acc[t] += neg ? -pr : pr;
+                    acx[t] += neg ? -cr : cr;
                 }
             }
         }
@@ -1740,7 +1759,11 @@ void launch_pass(const EvalCall& call, const PlanDev& pd, size_t k, double2* st,
         memset(&pio, 0, sizeof(pio));
         pio.alt_from = 1 << 30;
     }
-    const dim3 grid((unsigned)n_tiles, C);
+    // (large registers only: a small common state stays in the caches whatever the order, and with
+    // the tiles first all workgroups in flight read the same instance's records)
+    pio.n_states = C;
+    pio.state_first = (pio.F || pio.alt_from < C) && n >= 24;
+    const dim3 grid((unsigned)(n_tiles * C));
     if (pio.nz > 0)
         hipLaunchKernelGGL(k_tile_pass<1>, grid, dim3(kTT), kTileAmps * sizeof(double2), call.stream, st,
                            pd.swrec(slot0), pd.oprec(slot0), pd.pretab(slot0), pd.xrec(slot0), a, pio);
@@ -1813,6 +1836,11 @@ struct FuseInfo {
     bool main = false, h = false;
     bool main_write = true;   // the circuit's last pass still writes the final states (something else reads them)
     int n_tiles = 0;
+    // Every pure-X string lies within the qubits one pass of the Hadamard layer transforms: the passes
+    // then run side by side on the final states, each measuring its strings against the unshifted state
+    // behind that pass alone (hl.alt[k]), and none of them writes a state.
+    bool h_indep = false;
+    std::vector<int> term_hpass;   // per term: the pass of the layer that measures it, -1: none
 };
 
 int measure_states(const EvalCall& call, double2* st, int C, int64_t e0, int nb, double* partial,
@@ -1935,6 +1963,33 @@ int measure_states(const EvalCall& call, double2* st, int C, int64_t e0, int nb,
         }
         const bool hf = fu && fu->h;
         launch_mats(call, hl.pd, nullptr, 0, 0, C);
+        if (hf && fu->h_indep) {
+            const int64_t D = (int64_t)1 << n;
+            for (size_t k = 0; k < hl.pd.plan->passes.size(); ++k) {
+                PassIO io;
+                memset(&io, 0, sizeof(io));
+                io.alt_from = 1 << 30;
+                io.F = pair->fh + (int64_t)k * D;
+                io.partial = partial;
+                zb.nz = 0;
+                for (int o = 0; o < n_obs; ++o) {
+                    for (int t = call.obs.off[o]; t < call.obs.off[o + 1]; ++t) {
+                        if (fu->term_hpass[t] != (int)k) continue;
+                        io.z[io.nz] = (uint32_t)call.obs.x[t];
+                        io.bin[io.nz++] = -1;
+                        zb.z[zb.nz] = call.obs.x[t];
+                        zb.coef[zb.nz] = call.obs.coef[t];
+                        zb.col[zb.nz] = o;
+                        zb.bin[zb.nz++] = -1;
+                    }
+                }
+                if (zb.nz == 0) continue;
+                launch_pass(call, hl.pd, k, st, 0, C, &io);
+                zflush(zb, st, pair->fh, false, true);
+            }
+            VQA_HIP(hipGetLastError());
+            return VQA_OK;
+        }
         if (hf) {
             // the layer's last pass measures the strings and leaves the states unwritten
             const size_t np = hl.pd.plan->passes.size();
@@ -1991,8 +2046,7 @@ void fuse_plan(const EvalCall& call, const HLayer& hl, int64_t n_tiles, FuseInfo
             ++nmixed;
         }
     }
-    // (more than one round of kFusedZ entries costs the pass more than the separate reduction kernels take)
-    if (nz + M <= kFusedZ && nz + M > 0) {
+    if (nz + M <= kZBatch && nz + M > 0 && M <= (1 << kTileLow)) {
         for (int m = 0; m < M; ++m) {
             io->z[nz + m] = (uint32_t)(M - 1);
             io->bin[nz + m] = m;
@@ -2001,7 +2055,25 @@ void fuse_plan(const EvalCall& call, const HLayer& hl, int64_t n_tiles, FuseInfo
         fu->main = true;
         fu->main_write = hl.pd.plan || nmixed > 0;
     }
-    fu->h = hl.pd.plan && nx > 0 && nx <= kFusedZ;
+    fu->h = hl.pd.plan && nx > 0 && nx <= kZBatch;
+    if (fu->h) {
+        // the layer's gates are the Hadamards of the mask's qubits in ascending order
+        const TilePlan& hp = *hl.pd.plan;
+        int pass_of_qubit[64];
+        for (int q = 0, g = 0; q < 64; ++q) pass_of_qubit[q] = ((hl.mask >> q) & 1) ? hp.pass_of_gate[g++] : -1;
+        fu->h_indep = !getenv("VQA_NO_INDEP_H");
+        fu->term_hpass.assign(call.obs.n_terms, -1);
+        for (int t = 0; t < call.obs.n_terms && fu->h_indep; ++t) {
+            if (call.obs.x[t] == 0 || call.obs.z[t] != 0) continue;
+            int pk = -1;
+            for (int q = 0; q < 64; ++q) {
+                if (!((call.obs.x[t] >> q) & 1)) continue;
+                if (pk >= 0 && pass_of_qubit[q] != pk) fu->h_indep = false;
+                pk = pass_of_qubit[q];
+            }
+            fu->term_hpass[t] = pk;
+        }
+    }
 }
 
 }  // namespace
@@ -2158,15 +2230,16 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
     // so that the states that branch off in the same launch read it as it was)
     int rc = chunk_plan(call, 0.6, (size_t)200 << 30, Cmax, nb);
     if (rc) return rc;
-    if (Cmax < 5) VQA_FAIL(VQA_ENOMEM, "not enough free device memory for five %d-qubit states", n);
-    const int C = (int)std::min<int64_t>(Cmax - 4, std::max(m, 1));
-    Carver cv;
-    const size_t o_st = cv.add((size_t)(C + 4) * D * sizeof(double2));
-    const size_t o_tab = cv.add((size_t)(C + 2) * n_ops * sizeof(double2));
     FuseInfo fu;
     PassIO fio;
     memset(&fio, 0, sizeof(fio));
     fuse_plan(call, hl, D >> kTileBits, &fu, &fio);
+    const int n_alt = fu.h_indep ? (int)hl.pd.plan->passes.size() : 1;   // places behind the Hadamard layer
+    if (Cmax < 4 + n_alt) VQA_FAIL(VQA_ENOMEM, "not enough free device memory for %d %d-qubit states", 4 + n_alt, n);
+    const int C = (int)std::min<int64_t>(Cmax - 3 - n_alt, std::max(m, 1));
+    Carver cv;
+    const size_t o_st = cv.add((size_t)(C + 3 + n_alt) * D * sizeof(double2));
+    const size_t o_tab = cv.add((size_t)(C + 2) * n_ops * sizeof(double2));
     const size_t nb_part = std::max<size_t>(nb, (fu.main || fu.h) ? (size_t)fu.n_tiles : 0);
     const size_t o_part = cv.add((size_t)C * nb_part * kZBatch * 2 * sizeof(double));
     const size_t o_gate = cv.add(pd.image_bytes());
@@ -2206,8 +2279,8 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
     double2* F = st;
     double2* R = st + D;
     double2* S = st + 2 * D;
-    hl.alt = st + (int64_t)(C + 2) * D;   // the unshifted final state behind the Hadamard layer
-    double2* R2 = st + (int64_t)(C + 3) * D;
+    double2* R2 = st + (int64_t)(C + 2) * D;
+    hl.alt = st + (int64_t)(C + 3) * D;   // the unshifted final state behind the Hadamard layer (n_alt places)
     const unsigned gD = (unsigned)((D + kT - 1) / kT);
     HbmCommon h;
     h.n = n;
@@ -2229,6 +2302,17 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
         launch_all_passes(call, pd, F, 0, 1);
         rc = measure_states(call, F, 1, row0, nb, partial, nullptr, hl);   // leaves F alone: the layer goes onto hl.alt
         if (rc) return rc;
+        if (fu.h_indep) {
+            // the unshifted final state behind each pass of the layer alone
+            for (size_t k = 0; k < hl.pd.plan->passes.size(); ++k) {
+                PassIO io;
+                memset(&io, 0, sizeof(io));
+                io.alt_from = 1 << 30;
+                io.rd0 = F;
+                io.wr0 = hl.alt + (int64_t)k * D;
+                launch_pass(call, hl.pd, k, hl.alt, 0, 1, &io);
+            }
+        }
         if (n_unused > 0) {
             if (call.obs.n_obs > 0)
                 hipLaunchKernelGGL(k_copy_base, dim3((unsigned)((n_unused * call.obs.n_obs + kT - 1) / kT)), dim3(kT), 0,
