@@ -324,6 +324,19 @@ int vqa_irandom_stats_dev(int device, void* stream, const double* d_expect, int 
                           int has_scale, double w, double M_tot, uint64_t seed, double* d_out);
 
 /*
+ * Classifier MSE gradient from drawn class counts (vqa/QNN/myQNNs_classifier.py:1055-1156,
+ * MSE_grad_eval): d_counts[(b * (2P+1) + k) * 3 + c] = how often class c was read for sample b
+ * in instance k of its parameter-shift sweep (k = 0 unshifted, 1 + 2 i / 2 + 2 i = parameter i
+ * shifted up / down), d_shots[b * (2P+1) + k] = the shots of that instance.  With q = counts /
+ * shots:  d_label given (partial MSE):  d_grad[i] = mean_b (q0[label_b] - 1) (q+[label_b] - q-[label_b]);
+ * d_onehot given ([n_samples, 3], full MSE):  d_grad[i] = mean_b sum_c (q0[c] - onehot_b[c]) (q+[c] - q-[c]).
+ * Exactly one of d_label and d_onehot is not NULL.  Device pointers; deterministic summation order.
+ */
+int vqa_class_grad_dev(int device, void* stream, const int64_t* d_counts, const int64_t* d_shots,
+                       int64_t n_samples, int n_params, const int32_t* d_label, const double* d_onehot,
+                       double* d_grad);
+
+/*
  * Final state of ONE instance, interleaved (re, im) doubles, 2 * 2^n values,
  * host pointer.  For plumbing tests of the per-sample circuit.run(x) shim
  * (vqa/QNN/myQNNs_base.py:913); not a hot-path call.

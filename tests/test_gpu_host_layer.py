@@ -272,3 +272,39 @@ def test_iris_classifier_trains_on_gpu():
     assert last["train loss"] < first["train loss"] - 0.05
     assert last["train"] <= first["train"] + 1e-9
     assert res["total_shots"][-1] == 40 * 32 * 200 * (2 * clf.n_params + 1)
+
+
+@pytest.mark.parametrize("partial", [True, False])
+def test_class_grad_kernel_matches_numpy(partial):
+    """vqa_class_grad_dev against the same frequencies, products and means in NumPy
+    (myQNNs_classifier.py:1055-1156 with the counts given)."""
+    import ctypes as C
+
+    import torch
+
+    from vqa_amd import _lib
+
+    rng = np.random.default_rng(3)
+    B, P = 300, 7
+    K = 2 * P + 1
+    shots = rng.integers(5, 200, (B, K))
+    counts = np.stack([rng.multinomial(n, [0.2, 0.5, 0.3]) for n in shots.reshape(-1)]).reshape(B, K, 3)
+    y = rng.integers(0, 3, B)
+    q = counts / shots[:, :, None]
+    if partial:
+        ps = q[np.arange(B), :, y]
+        want = ((ps[:, 0] - 1.0)[:, None] * (ps[:, 1::2] - ps[:, 2::2])).mean(0)
+    else:
+        want = ((q[:, 0, :] - np.eye(3)[y])[:, None, :] * (q[:, 1::2, :] - q[:, 2::2, :])).sum(-1).mean(0)
+    dev = torch.device("cuda:0")
+    d_c = torch.from_numpy(counts.astype(np.int64)).to(dev)
+    d_n = torch.from_numpy(shots.astype(np.int64)).to(dev)
+    d_lab = torch.from_numpy(y.astype(np.int32)).to(dev) if partial else None
+    d_hot = None if partial else torch.from_numpy(np.eye(3)[y]).to(dev)
+    out = torch.empty(P, dtype=torch.float64, device=dev)
+    ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    _lib.check(_lib.lib().vqa_class_grad_dev(0, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream), ptr(d_c), ptr(d_n),
+                                             B, P, ptr(d_lab), ptr(d_hot), ptr(out)))
+    assert np.max(np.abs(out.cpu().numpy() - want)) < 1e-14
+    with pytest.raises(_lib.VqaError):
+        _lib.check(_lib.lib().vqa_class_grad_dev(0, None, ptr(d_c), ptr(d_n), B, P, None, None, ptr(out)))

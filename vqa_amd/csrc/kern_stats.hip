@@ -308,7 +308,49 @@ __global__ __launch_bounds__(kT) void k_irandom_stats(IRandomArgs a) {
     }
 }
 
+// ---- classifier MSE gradient from drawn class counts ----------------------------------------------
+// vqa/QNN/myQNNs_classifier.py:1055-1156 (MSE_grad_eval): with q = counts / shots the class
+// frequencies of the unshifted (k = 0) and shifted (k = 1 + 2 i, 2 + 2 i) circuits of sample b,
+//   partial MSE:  grad[i] = mean_b (q0[y_b] - 1) (q+[y_b] - q-[y_b])
+//   full MSE:     grad[i] = mean_b sum_c (q0[c] - onehot_b[c]) (q+[c] - q-[c]).
+// One workgroup per component, a thread takes every kT-th sample, fixed-order tree sum.
+__global__ __launch_bounds__(kT) void k_class_grad(const int64_t* __restrict__ counts, const int64_t* __restrict__ shots,
+                                                   int64_t B, int P, const int32_t* __restrict__ label,
+                                                   const double* __restrict__ y1hot, double* __restrict__ grad) {
+    __shared__ double red[kT];
+    const int i = blockIdx.x, tid = threadIdx.x, K = 2 * P + 1;
+    double acc = 0.0;
+    for (int64_t b = tid; b < B; b += kT) {
+        const int64_t r0 = b * K, rp = r0 + 1 + 2 * i, rm = rp + 1;
+        const double n0 = (double)shots[r0], np_ = (double)shots[rp], nm = (double)shots[rm];
+        if (label) {
+            const int y = label[b];
+            acc += ((double)counts[3 * r0 + y] / n0 - 1.0) * ((double)counts[3 * rp + y] / np_ - (double)counts[3 * rm + y] / nm);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                acc += ((double)counts[3 * r0 + c] / n0 - y1hot[3 * b + c]) *
+                       ((double)counts[3 * rp + c] / np_ - (double)counts[3 * rm + c] / nm);
+        }
+    }
+    red[tid] = acc;
+    __syncthreads();
+    for (int h = kT / 2; h > 0; h >>= 1) {
+        if (tid < h) red[tid] += red[tid + h];
+        __syncthreads();
+    }
+    if (tid == 0) grad[i] = red[0] / (double)B;
+}
+
 }  // namespace
+
+int class_grad_launch(hipStream_t stream, const int64_t* d_counts, const int64_t* d_shots, int64_t B, int P,
+                      const int32_t* d_label, const double* d_y1hot, double* d_grad) {
+    if (P <= 0 || B <= 0) return VQA_OK;
+    hipLaunchKernelGGL(k_class_grad, dim3(P), dim3(kT), 0, stream, d_counts, d_shots, B, P, d_label, d_y1hot, d_grad);
+    VQA_HIP(hipGetLastError());
+    return VQA_OK;
+}
 
 size_t mse_stats_workspace_bytes(int64_t B, int P) {
     const int64_t tiles = (B + kTile - 1) / kTile;

@@ -855,6 +855,20 @@ int vqa_irandom_stats_dev(int device, void* stream, const double* d_expect, int 
                                 kind, has_scale, w, M_tot, seed, d_out);
 }
 
+int vqa_class_grad_dev(int device, void* stream, const int64_t* d_counts, const int64_t* d_shots, int64_t n_samples,
+                       int n_params, const int32_t* d_label, const double* d_onehot, double* d_grad) {
+    if (n_samples < 0 || n_params < 0) VQA_FAIL(VQA_EINVAL, "n_samples and n_params must be >= 0");
+    if (n_samples == 0 || n_params == 0) return VQA_OK;
+    if (!d_counts || !d_shots || !d_grad) VQA_FAIL(VQA_EINVAL, "counts, shots and grad must not be NULL");
+    if ((d_label != nullptr) == (d_onehot != nullptr))
+        VQA_FAIL(VQA_EINVAL, "exactly one of the class labels (partial MSE) and the one-hot labels (full MSE) is given");
+    int count = 0;
+    VQA_HIP(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) VQA_FAIL(VQA_ENODEVICE, "device %d out of range (%d visible)", device, count);
+    VQA_HIP(hipSetDevice(device));
+    return class_grad_launch((hipStream_t)stream, d_counts, d_shots, n_samples, n_params, d_label, d_onehot, d_grad);
+}
+
 int vqa_statevector(vqa_circuit* c, int device, const double* theta, const double* input_row,
                     int shift_param, double shift_val, double* out_state) {
     if (!c) VQA_FAIL(VQA_EINVAL, "circuit handle is NULL");

@@ -210,6 +210,8 @@ int mse_stats_launch(hipStream_t stream, const double* d_E, const double* d_est,
                      int want_var, double n0, int second_order, double* d_workspace, double* d_out, double* d_m0,
                      double* d_gd);
 
+int class_grad_launch(hipStream_t stream, const int64_t* d_counts, const int64_t* d_shots, int64_t B, int P,
+                      const int32_t* d_label, const double* d_y1hot, double* d_grad);
 int irandom_stats_launch(hipStream_t stream, const double* d_expect, int n_obs, const int32_t* d_label, const double* d_y,
                          const int64_t* d_shots, const int32_t* d_seg, const double* d_n_list, int C, int kind,
                          int has_scale, double w, double M_tot, uint64_t seed, double* d_out);

@@ -387,14 +387,20 @@ class myQNN_classifier(myQNN_base):
             c = k[:, :3] + sample_counts(third, k[:, 3], seed, stream_id=1)
         else:
             c = torch.stack([k[:, 0] + k[:, 3], k[:, 1], k[:, 2]], dim=1)
-        q = c.reshape(B, K, 3).to(torch.float64) / n_inst.to(torch.float64)[:, :, None]            # class frequencies
+        # class frequencies, products and batch means: one kernel (vqa_class_grad_dev)
+        import ctypes as C
+
+        from . import _lib
+        counts = c.to(torch.int64).contiguous()
+        grad = torch.empty(P, dtype=torch.float64, device=dev)
+        d_lab = d_hot = None
         if partial_MSE:
-            y = torch.from_numpy(np.asarray(y_eval, dtype=np.int64)).to(dev)
-            ps = q[torch.arange(B, device=dev), :, y]                                               # [B, K]
-            grad = ((ps[:, 0] - 1.0)[:, None] * (ps[:, 1::2] - ps[:, 2::2])).mean(0)
+            d_lab = torch.from_numpy(np.asarray(y_eval, dtype=np.int32)).to(dev)
         else:
-            err = q[:, 0, :] - torch.from_numpy(np.asarray(y_1hot, dtype=np.float64)).to(dev)
-            grad = (err[:, None, :] * (q[:, 1::2, :] - q[:, 2::2, :])).sum(-1).mean(0)
+            d_hot = torch.from_numpy(np.ascontiguousarray(y_1hot, dtype=np.float64)).to(dev)
+        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        _lib.check(_lib.lib().vqa_class_grad_dev(dev.index or 0, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream),
+                                                 ptr(counts), ptr(n_inst.contiguous()), B, P, ptr(d_lab), ptr(d_hot), ptr(grad)))
         self.circuit_counter[0] += B * K
         self.call_counter[0] += B * K
         self.shots_counter[0] += int(n0.sum() + 2 * n_all.sum())
