@@ -283,18 +283,20 @@ def hbm_traffic_per_launch(evals):
 
 
 def roofline(bytes_alg, flops_alg, evals, kern_ms, measured):
-    """Position of the sweep kernel on the FP64 vector roofline.  achieved / frac: the FP64 flops the
-    kernel executes (SQ_INSTS_VALU_{FMA,MUL,ADD}_F64 of the committed profile, per evaluation) at the
-    launch duration measured now.  alg_*: the unfused gate list's work at the same duration."""
+    """Position of the sweep kernel on the FP64 roofline.  achieved / frac: the FP64 flops the kernel
+    executes (SQ_INSTS_VALU_{FMA,MUL,ADD}_F64 and SQ_INSTS_VALU_MFMA_MOPS_F64 of the committed profile,
+    per evaluation) at the launch duration measured now.  alg_*: the unfused gate list's work at the
+    same duration."""
     per_s = evals / (kern_ms * 1e-3)
     alg_tflops = flops_alg * per_s / 1e12
     alg_gbs = bytes_alg * per_s / 1e9
-    ex = profiled("fp64_flops_per_eval")
+    ex_valu, ex_mfma = profiled("fp64_flops_per_eval"), profiled("mfma_f64_flops_per_eval") or 0.0
+    ex = None if ex_valu is None else ex_valu + ex_mfma
     ex_tflops = None if ex is None else ex * per_s / 1e12
     r = {
         "kernel": "k_reg_psr",
-        # FP64 vector ALU: the kernel issues v_fma_f64 / v_mul_f64, no MFMA (on gfx950 the FP64 MFMA
-        # peak equals the FP64 vector peak, 78.6 TFLOP/s, and a 2x2 gate is no GEMM)
+        # the FP64 pipe: v_fma_f64 / v_mul_f64 and, for the rotations on lane bits 4 and 5, v_mfma_f64_4x4x4
+        # (on gfx950 the FP64 matrix peak equals the FP64 vector peak, 78.6 TFLOP/s, and the two share the pipe)
         "bound": "valu_fp64",
         "achieved": ex_tflops,
         "peak": FP64_PEAK_TFLOPS,
@@ -304,7 +306,10 @@ def roofline(bytes_alg, flops_alg, evals, kern_ms, measured):
         "kernel_ms_per_launch": kern_ms,
         "evals_per_launch": evals,
         "executed_fp64_flops_per_eval": ex,
-        "fp64_issue_frac": None if ex is None else profiled("fp64_wave_instr_per_eval") * per_s * 4.0 / (1024 * 2.4e9),
+        "executed_fp64_flops_per_eval_matrix_unit": ex_mfma,
+        # share of the launch the FP64 pipe is issuing: 4 cycles per vector instruction, 16 per matrix instruction
+        "fp64_issue_frac": None if ex is None else (profiled("fp64_wave_instr_per_eval") * 4.0 +
+                                                    (profiled("mfma_f64_wave_instr_per_eval") or 0.0) * 16.0) * per_s / (1024 * 2.4e9),
         "profile_source": profiled_str("source"),
         # the submitted, unfused gate list priced the same way (ratios above 1: work the engine never does)
         "alg_flops_per_eval": flops_alg,

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/hbm_traffic.json from the FETCH_SIZE / WRITE_SIZE / FP64 instruction passes of tools/prof.sh.
+"""profiles/hbm_traffic.json from the FETCH_SIZE / WRITE_SIZE / FP64 instruction (vector and matrix unit) passes of tools/prof.sh.
 
 usage: tools/hbm_traffic.py gpurun_out/prof_<tag> <launches> <evals per launch> <kernel substring>
 
@@ -22,6 +22,7 @@ def total(name):
 
 
 fma, mul, add = (total("SQ_INSTS_VALU_%s_F64" % k) / launches for k in ("FMA", "MUL", "ADD"))
+mfma = total("SQ_INSTS_VALU_MFMA_MOPS_F64") / launches   # one count per v_mfma_f64_4x4x4 of a wave: 256 FMAs
 fetch = 2.0 * 1024.0 * total("FETCH_SIZE") / launches
 write = 1024.0 * total("WRITE_SIZE") / launches
 out = {
@@ -31,6 +32,10 @@ out = {
     # executed FP64 work of the kernel (wave64 instructions; an FMA is two flops per lane)
     "fp64_wave_instr_per_eval": (fma + mul + add) / evals,
     "fp64_flops_per_eval": 64.0 * (2.0 * fma + mul + add) / evals,
+    # FP64 work on the matrix unit (the rotations on lane bits 4 and 5), which shares the FP64 pipe
+    # with the vector instructions: 512 flops and 16 cycles per instruction of a wave
+    "mfma_f64_wave_instr_per_eval": mfma / evals,
+    "mfma_f64_flops_per_eval": 512.0 * mfma / evals,
     "corrections": "FETCH_SIZE x2 (gfx950 wide loads), both counters KiB -> bytes",
     "source": os.path.basename(os.path.normpath(d)),
 }

@@ -15,3 +15,5 @@ timeout -s KILL 300 rocprofv3 --output-format csv --pmc GRBM_GUI_ACTIVE GRBM_COU
 # HBM traffic: FETCH_SIZE and WRITE_SIZE do not fit one pass
 timeout -s KILL 300 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $out/pmc4 -o pmc4 -- python3 bench.py "$@" --no-cpu-baseline --no-other-configs > $out/pmc4.log 2>&1
 timeout -s KILL 300 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $out/pmc5 -o pmc5 -- python3 bench.py "$@" --no-cpu-baseline --no-other-configs > $out/pmc5.log 2>&1
+# matrix-unit FP64 (the lane rotations on bits 4 and 5)
+timeout -s KILL 300 rocprofv3 --output-format csv --pmc SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES -d $out/pmc6 -o pmc6 -- python3 bench.py "$@" --no-cpu-baseline --no-other-configs > $out/pmc6.log 2>&1
