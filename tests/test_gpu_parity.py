@@ -414,6 +414,10 @@ def test_streaming_sweep_with_pauli_sums(n, d):
         tfim.add_operator(0.7, f"X {i}")
     mixed = Observable(n)
     mixed.add_operator(0.5, "X 0 X 5")
+    if n == 15:
+        # a pure-X string across two passes of the Hadamard layer: the layer's passes then run one after
+        # the other (only the last one measures) instead of side by side
+        mixed.add_operator(0.25, f"X 0 X {n - 1}")
     mixed.add_operator(-0.3, f"Y 2 Z {n - 1}")
     mixed.add_operator(0.2, f"X 1 Z 3 Y {n - 2}")
     mixed.add_operator(0.1, "")

@@ -416,7 +416,8 @@ __device__ __forceinline__ int xor_fetch32(int v) {
     else if constexpr (LB == 0) return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);        // quad_perm [1,0,3,2]
     else if constexpr (LB == 1) return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
     else if constexpr (LB == 2) {
-        int t = __builtin_amdgcn_update_dpp(0, v, 0x104, 0xF, 0x5, false);  // row_shl:4 into banks 0,2
+        // (the first move writes every lane, so that it needs no defined old value: one instruction less)
+        int t = __builtin_amdgcn_mov_dpp(v, 0x104, 0xF, 0xF, true);         // row_shl:4: right for banks 0,2
         return __builtin_amdgcn_update_dpp(t, v, 0x114, 0xF, 0xA, false);    // row_shr:4 into banks 1,3
     } else return __builtin_amdgcn_mov_dpp(v, 0x128, 0xF, 0xF, true);  // row_ror:8
 }
