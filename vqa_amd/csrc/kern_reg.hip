@@ -1303,11 +1303,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : BLOCK == 512 ? 2 : BLOCK
             }
             old_m = id_m; old_b = id_b; old_a = id_a;
             if (r == NR) break;   // (the last pass only undoes the last patch)
-            __syncthreads();
-            VQA_STAMP(1)
-            // the next run's record travels while this run computes
-            if (ri + 1 < NL && (tid & 63) < 8) nx = recs[(size_t)live[ri + 1] * 8 + (tid & 63)];
-
+            // the checkpoint is on its way while thread 0's patch settles (the barrier orders LDS only)
             double2 amp[kRegAmps];
             int pc0 = 0;
             if (rdiag >= 0) {
@@ -1318,6 +1314,10 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : BLOCK == 512 ? 2 : BLOCK
                 for (int q = 0; q < kRegAmps; ++q) amp[q] = make_double2(0.0, 0.0);
                 if (t == 0) amp[0].x = 1.0;
             }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            VQA_STAMP(1)
+            // the next run's record travels while this run computes
+            if (ri + 1 < NL && (tid & 63) < 8) nx = recs[(size_t)live[ri + 1] * 8 + (tid & 63)];
             if (!VQA_ABL(a, 8)) run_phases<true>(amp, pp, cx, pc0, rdiag >= 0, r < 0);
             VQA_STAMP(2)
             if (r < 0) store_state(amp, cx.area, (unsigned)ND * cx.image_bytes, BLOCK, tid);
