@@ -1062,7 +1062,9 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : BLOCK == 512 ? 2 : VQA_W
     constexpr bool SCALED = BLOCK > 64;
     extern __shared__ double2 smem[];
     const Prog pp = load_prog(a.prog);
-    const int n = pp.H->n, T = pp.H->T, S = pp.H->S;
+    // (above one wave a workgroup is one state and the thread bits are its size: a constant unrolls the loops over them)
+    const int T = BLOCK == 128 ? 7 : BLOCK == 256 ? 8 : BLOCK == 512 ? 9 : BLOCK == 1024 ? 10 : pp.H->T;
+    const int n = pp.H->n, S = pp.H->S;
     const int NU = pp.H->n_uent, N1 = pp.H->n_d1, N2 = pp.H->n_d2;
     const int tab_stride = NU + N1 + N2;
     const int tid = threadIdx.x;
@@ -1196,7 +1198,10 @@ template <int BLOCK>
 __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : BLOCK == 512 ? 2 : BLOCK <= 128 ? VQA_SMALL_WAVES : VQA_WAVES) void k_reg_psr(RegArgs a) {
     extern __shared__ double2 smem[];
     const Prog pp = load_prog(a.prog);
-    const int n = pp.H->n, T = pp.H->T;
+    // one state per workgroup: the thread bits are the workgroup's size (a constant lets the loops over
+    // them unroll, so that their table reads are issued together)
+    constexpr int T = BLOCK == 64 ? 6 : BLOCK == 128 ? 7 : BLOCK == 256 ? 8 : BLOCK == 512 ? 9 : 10;
+    const int n = pp.H->n;
     const int NU = pp.H->n_uent, N1 = pp.H->n_d1, N2 = pp.H->n_d2, ND = pp.H->n_ddesc;
     const int P = pp.H->n_params, NR = pp.H->n_runs;
     const int tid = threadIdx.x;

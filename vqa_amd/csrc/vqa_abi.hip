@@ -291,6 +291,12 @@ static void cone_reg_program_host(const EvalCall& call) {
         if (reg_compile(call.c->n_qubits, call.c->n_theta, live, rp.get(), &why) &&
             reg_engine_can_sweep(*rp) == reg_engine_can_sweep(*call.c->reg))
             cone.reg = rp;
+        if (getenv("VQA_PLAN_DEBUG") && cone.reg) {
+            fprintf(stderr, "[vqa] register program without %d gates: %d phases, %d transpositions, final layout (position: qubit)",
+                    cone.n_gate_dead, rp->hdr.n_phases, rp->n_xpose);
+            for (int p = 0; p < call.c->n_qubits; ++p) fprintf(stderr, " %d:%d", p, (int)rp->hdr.final_qubit_at_pos[p]);
+            fprintf(stderr, "\n");
+        }
     }
 }
 
