@@ -188,12 +188,11 @@ __device__ __forceinline__ double elem_angle_c(const VQA_CAS ElemGate* g, const 
 // inserted in front of that rotation (derivative direction of the parameter).
 // gp = the unit factor of the exact 2x2 that the engine leaves out: e^{i d}, times i
 // in the second scaled lane form, times G when there is no stage in front to take it.
-template <bool SCALED>
-__device__ __forceinline__ void compute_uentry(const Prog& pp, int u, const double* theta, const double* row,
-                                               int sparam, double sval, int pparam, double2& m, cplx& A, cplx& G,
-                                               cplx& gp) {
+// the 2x2 of U-entry u multiplied out (see compute_uentry for the arguments)
+__device__ __forceinline__ void uentry_product(const Prog& pp, int u, const double* theta, const double* row, int sparam,
+                                               double sval, int pparam, cplx& m00, cplx& m01, cplx& m10, cplx& m11) {
     const int ubegin = pp.uent[u].begin, ucount = pp.uent[u].count;
-    cplx m00 = { 1, 0 }, m01 = { 0, 0 }, m10 = { 0, 0 }, m11 = { 1, 0 };
+    m00 = { 1, 0 }; m01 = { 0, 0 }; m10 = { 0, 0 }; m11 = { 1, 0 };
     for (int j = 0; j < ucount; ++j) {
         const VQA_CAS ElemGate* g = pp.elems + ubegin + j;
         const int kind = g->kind;
@@ -229,6 +228,14 @@ __device__ __forceinline__ void compute_uentry(const Prog& pp, int u, const doub
         m10 = { c0.x + c1.x, c0.y + c1.y };
         m11 = { d0.x + d1.x, d0.y + d1.y };
     }
+}
+
+template <bool SCALED>
+__device__ __forceinline__ void compute_uentry(const Prog& pp, int u, const double* theta, const double* row,
+                                               int sparam, double sval, int pparam, double2& m, cplx& A, cplx& G,
+                                               cplx& gp) {
+    cplx m00, m01, m10, m11;
+    uentry_product(pp, u, theta, row, sparam, sval, pparam, m00, m01, m10, m11);
     const double a00 = sqrt(m00.x * m00.x + m00.y * m00.y), a01 = sqrt(m01.x * m01.x + m01.y * m01.y);
     const double inv = 1.0 / sqrt(a00 * a00 + a01 * a01);
     const cplx dA = cmul(m00, m11), dB = cmul(m01, m10);
@@ -646,7 +653,14 @@ __device__ __forceinline__ void do_xpose(double2 (&amp)[kRegAmps], const Prog& p
 
 // One diagonal stage (descriptor did).
 __device__ __forceinline__ void do_diag(double2 (&amp)[kRegAmps], const Prog& pp, const Ctx& cx, int did) {
-    const VQA_CAS DDesc* dd = pp.ddesc + did;
+    // the whole descriptor in one go (field by field each scalar load is waited for where it is used)
+    static_assert(sizeof(DDesc) == 48, "DDesc is fetched as three 16-byte scalar loads");
+    const VQA_CAS i32x4* ddv = (const VQA_CAS i32x4*)(pp.ddesc + did);
+    const i32x4 dd0 = ddv[0], dd1 = ddv[1], dd2 = ddv[2];
+    struct { int ph1_base, tt_begin, tt_count, rt_begin, rt_count, rr_begin, rr_count, sign_id; } ddl =
+        { dd0.x, dd0.y, dd0.z, dd0.w, dd1.x, dd1.y, dd1.z, dd1.w };
+    (void)dd2;
+    const auto* dd = &ddl;
     const double2* p1 = cx.ph1 + dd->ph1_base;
     const int t = cx.t();
     // thread-only factor
@@ -1131,6 +1145,71 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : BLOCK == 512 ? 2 : VQA_W
     }
 }
 
+// A one-qubit 2x2 C (complex) on the qubit at one position of the layout, in place (late resumption of a
+// sweep run, see ParamInfo).  Register bit: the pairs of the thread's own amplitudes; lane bit: each lane holds
+// one amplitude of the pair and fetches the other.
+//   (a0, a1) <- (c00 a0 + c01 a1, c10 a0 + c11 a1)
+__device__ __forceinline__ void cpair_inplace(double& a0x, double& a0y, double& a1x, double& a1y, double2 c00, double2 c01,
+                                              double2 c10, double2 c11) {
+    double t0, t1, t2, t3;
+    asm("v_mul_f64 %4, %8, %0\n\tv_mul_f64 %5, %8, %1\n\tv_mul_f64 %6, %12, %0\n\tv_mul_f64 %7, %12, %1\n\t"
+        "v_fma_f64 %4, -%9, %1, %4\n\tv_fma_f64 %5, %9, %0, %5\n\tv_fma_f64 %6, -%13, %1, %6\n\tv_fma_f64 %7, %13, %0, %7\n\t"
+        "v_fma_f64 %4, %10, %2, %4\n\tv_fma_f64 %5, %10, %3, %5\n\tv_fma_f64 %6, %14, %2, %6\n\tv_fma_f64 %7, %14, %3, %7\n\t"
+        "v_fma_f64 %0, -%11, %3, %4\n\tv_fma_f64 %1, %11, %2, %5\n\tv_fma_f64 %4, -%15, %3, %6\n\tv_fma_f64 %3, %15, %2, %7\n\t"
+        "v_mov_b64 %2, %4"
+        : "+v"(a0x), "+v"(a0y), "+v"(a1x), "+v"(a1y), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(c00.x), "v"(c00.y), "v"(c01.x), "v"(c01.y), "v"(c10.x), "v"(c10.y), "v"(c11.x), "v"(c11.y));
+}
+template <int J>
+__device__ __forceinline__ void apply_creg(double2 (&amp)[kRegAmps], double2 c00, double2 c01, double2 c10, double2 c11) {
+    constexpr int lo = (1 << J) - 1;
+#pragma unroll
+    for (int k = 0; k < kRegAmps / 2; ++k) {
+        const int r0 = ((k & ~lo) << 1) | (k & lo), r1 = r0 | (1 << J);
+        cpair_inplace(amp[r0].x, amp[r0].y, amp[r1].x, amp[r1].y, c00, c01, c10, c11);
+    }
+}
+//   a <- cs a + co p  (cs, co: the lane's own and the partner's coefficient)
+__device__ __forceinline__ void clane_inplace(double& ax, double& ay, double px, double py, double csx, double csy, double cox,
+                                              double coy) {
+    double t0, t1;
+    asm("v_mul_f64 %2, %6, %0\n\tv_mul_f64 %3, %6, %1\n\t"
+        "v_fma_f64 %2, -%7, %1, %2\n\tv_fma_f64 %3, %7, %0, %3\n\t"
+        "v_fma_f64 %2, %8, %4, %2\n\tv_fma_f64 %3, %8, %5, %3\n\t"
+        "v_fma_f64 %0, -%9, %5, %2\n\tv_fma_f64 %1, %9, %4, %3"
+        : "+v"(ax), "+v"(ay), "=&v"(t0), "=&v"(t1)
+        : "v"(px), "v"(py), "v"(csx), "v"(csy), "v"(cox), "v"(coy));
+}
+template <int LB>
+__device__ __forceinline__ void apply_clane(double2 (&amp)[kRegAmps], double2 c00, double2 c01, double2 c10, double2 c11,
+                                            int lane) {
+    const bool up = (lane >> LB) & 1;
+    const double csx = up ? c11.x : c00.x, csy = up ? c11.y : c00.y, cox = up ? c10.x : c01.x, coy = up ? c10.y : c01.y;
+    // the cross-lane moves read registers that inline assembly may have written last
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 1");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < kRegAmps; ++r) {
+        const double px = xor_fetch<LB, false>(amp[r].x), py = xor_fetch<LB, false>(amp[r].y);
+        clane_inplace(amp[r].x, amp[r].y, px, py, csx, csy, cox, coy);
+    }
+}
+// mask = 1 << position (one bit per alternative, tested one after the other: each block updates the amplitudes in place)
+__device__ __forceinline__ void apply_correction(double2 (&amp)[kRegAmps], const double2* rec, int mask, int lane) {
+    const double2 c00 = rec[0], c01 = rec[1], c10 = rec[2], c11 = rec[7];
+    if (mask & 1) apply_creg<0>(amp, c00, c01, c10, c11);
+    if (mask & 2) apply_creg<1>(amp, c00, c01, c10, c11);
+    if (mask & 4) apply_creg<2>(amp, c00, c01, c10, c11);
+    if (mask & 8) apply_creg<3>(amp, c00, c01, c10, c11);
+    if (mask & 16) apply_clane<0>(amp, c00, c01, c10, c11, lane);
+    if (mask & 32) apply_clane<1>(amp, c00, c01, c10, c11, lane);
+    if (mask & 64) apply_clane<2>(amp, c00, c01, c10, c11, lane);
+    if (mask & 128) apply_clane<3>(amp, c00, c01, c10, c11, lane);
+    if (mask & 256) apply_clane<4>(amp, c00, c01, c10, c11, lane);
+    if (mask & 512) apply_clane<5>(amp, c00, c01, c10, c11, lane);
+}
+
 // ---- full parameter-shift sweeps ------------------------------------------------------
 // a.E = number of samples; sample j = sel[j] (or j); outputs at instance
 // j * (2P+1) + k.  One state per workgroup (BLOCK = 2^T >= 64 threads).
@@ -1144,10 +1223,48 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : BLOCK == 512 ? 2 : VQA_W
 // then the runs one after the other, each: thread 0 undoes the previous patch
 // and applies this run's, everybody resumes from the checkpoint and measures.
 // The record of the next run is fetched while the current one computes.
-template <int BLOCK, bool SCALED = true>
+template <int BLOCK, bool SCALED = true, bool LATE = false>
 __device__ __forceinline__ void make_run_record(const RegArgs& a, const Prog& pp, int r, const double* row, int NU, int N1,
                                                 RunRec* out) {
     const int i = pp.runs[r].param, variant = pp.runs[r].variant;
+    if (LATE && variant == 0 && pp.params[i].late_mask != 0) {
+        // resumption behind the parameter's own U-stage (see ParamInfo): C = M' M^-1, taken into the frame of
+        // the checkpoint in front of the diagonal stage, whose table still holds this 2x2's factor
+        // diag(A, conj A): C' = diag(A, conj A)^-1 C diag(A, conj A)
+        const int index = pp.refs[pp.params[i].ref_begin].index;
+        const double coef = pp.refs[pp.params[i].ref_begin].coef_sum;
+        cplx m00, m01, m10, m11, n00, n01, n10, n11;
+        uentry_product(pp, index, a.theta, row, -1, 0.0, -1, m00, m01, m10, m11);
+        uentry_product(pp, index, a.theta, row, -1, 0.0, i, n00, n01, n10, n11);
+        auto add = [](cplx x, cplx y) { return cplx{ x.x + y.x, x.y + y.y }; };
+        cplx c00 = add(cmul(n00, cconj(m00)), cmul(n01, cconj(m01)));
+        cplx c01 = add(cmul(n00, cconj(m10)), cmul(n01, cconj(m11)));
+        cplx c10 = add(cmul(n10, cconj(m00)), cmul(n11, cconj(m01)));
+        cplx c11 = add(cmul(n10, cconj(m10)), cmul(n11, cconj(m11)));
+        double2 mv;
+        cplx A, G, gp;
+        compute_uentry<SCALED>(pp, index, a.theta, row, -1, 0.0, -1, mv, A, G, gp);
+        const cplx A2 = cmul(A, A);
+        c01 = cmul(c01, cconj(A2));
+        c10 = cmul(c10, A2);
+        double sk, ck;
+        sincos(0.5 * coef * a.spec.shift, &sk, &ck);
+        RunRec rec;
+        rec.m[0] = c00.x; rec.m[1] = c00.y;
+        rec.fb[0] = c01.x; rec.fb[1] = c01.y;
+        rec.fa[0] = c10.x; rec.fa[1] = c10.y;
+        rec.c11[0] = c11.x; rec.c11[1] = c11.y;
+        rec.rho[0] = 1.0; rec.rho[1] = 0.0;
+        rec.cs[0] = ck; rec.cs[1] = sk;
+        rec.ids[0] = rec.ids[1] = rec.ids[2] = -1;
+        rec.ids[3] = pp.params[i].late_mask;
+        rec.out[0] = 1;
+        rec.out[1] = 1 + 2 * i;
+        rec.out[2] = pp.params[i].late_diag;
+        rec.out[3] = pp.params[i].late_pc;
+        *out = rec;
+        return;
+    }
     const int ref_count = pp.params[i].ref_count;
     const int kind = ref_count > 0 ? pp.refs[pp.params[i].ref_begin].kind : -1;
     const int index = ref_count > 0 ? pp.refs[pp.params[i].ref_begin].index : 0;
@@ -1190,7 +1307,7 @@ __device__ __forceinline__ void make_run_record(const RegArgs& a, const Prog& pp
     rec.out[1] = 1 + 2 * i + (variant == 2 ? 1 : 0);
     rec.out[2] = pp.params[i].resume_diag;
     rec.out[3] = pp.params[i].resume_pc;
-    rec.pad[0] = rec.pad[1] = 0.0;
+    rec.c11[0] = rec.c11[1] = 0.0;
     *out = rec;
 }
 
@@ -1264,7 +1381,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : BLOCK == 512 ? 2 : BLOCK
         __syncthreads();
         prep_tables<true, true>(a, pp, tabs, j, 1, NU, N1, N2, tid, BLOCK);
         for (int r = tid; r < NR; r += BLOCK)
-            make_run_record<BLOCK>(a, pp, r, row, NU, N1, a.recs + (size_t)blockIdx.x * NR + r);
+            make_run_record<BLOCK, true, true>(a, pp, r, row, NU, N1, a.recs + (size_t)blockIdx.x * NR + r);
         __threadfence_block();
         VQA_STAMP(0)
 
@@ -1277,12 +1394,13 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : BLOCK == 512 ? 2 : BLOCK
             const int r = ri < 0 ? -1 : ri < NL ? live[ri] : NR;
             VQA_STAMP0
             __syncthreads();   // the previous run is over (tables free); its successor's record is in pz
-            int id_m = -1, id_b = -1, id_a = -1, mode = 0, kout = 0, rdiag = -1, rpc = 0;
+            int id_m = -1, id_b = -1, id_a = -1, mode = 0, kout = 0, rdiag = -1, rpc = 0, late = 0;
             if (r >= 0 && r < NR) {
                 const int4 ids = *(const int4*)&pz[5], o = *(const int4*)&pz[6];
                 id_m = __builtin_amdgcn_readfirstlane(ids.x);
                 id_b = __builtin_amdgcn_readfirstlane(ids.y);
                 id_a = __builtin_amdgcn_readfirstlane(ids.z);
+                late = __builtin_amdgcn_readfirstlane(ids.w);
                 mode = __builtin_amdgcn_readfirstlane(o.x);
                 kout = __builtin_amdgcn_readfirstlane(o.y);
                 rdiag = __builtin_amdgcn_readfirstlane(o.z);
@@ -1320,6 +1438,9 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : BLOCK == 512 ? 2 : BLOCK
                 if (t == 0) amp[0].x = 1.0;
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            // late resumption: the checkpoint is the unshifted state behind the parameter's U-stage; the
+            // run's state there differs by a 2x2 on the one qubit (the record is not replaced before the end of the run)
+            if (late) apply_correction(amp, pz, late, cx.lane());
             VQA_STAMP(1)
             // the next run's record travels while this run computes
             if (ri + 1 < NL && (tid & 63) < 8) nx = recs[(size_t)live[ri + 1] * 8 + (tid & 63)];

@@ -540,6 +540,26 @@ bool reg_compile(int n, int n_theta, const std::vector<vqa_op>& gate_list, RegPr
                 pi.resume_diag = rd;   // -1: the first U-stage changes -> restart
             }
             pi.resume_pc = pi.resume_diag >= 0 ? P.ddesc[pi.resume_diag].pc : 0;
+            pi.late_diag = -1;
+            pi.late_pc = 0;
+            pi.late_mask = 0;
+            pi.pad = 0;
+        }
+        // resumption behind the parameter's own U-stage (see ParamInfo)
+        for (int u = 0; u + 1 < NU; ++u) {
+            for (auto& kv : uidx[u]) {
+                const int pos = dlayout[u].pos_of[kv.first];
+                if (pos >= R + L) continue;   // a wave bit: no partner within the wave
+                for (int i = 0; i < n_theta; ++i) {
+                    ParamInfo& pi = P.params[i];
+                    if (pi.ref_count != 1) continue;
+                    const PatchRef& ref = P.refs[pi.ref_begin];
+                    if (ref.kind != 0 || ref.index != kv.second || ref.coef_sum == 0.0) continue;
+                    pi.late_diag = u;
+                    pi.late_pc = P.ddesc[u].pc;
+                    pi.late_mask = 1 << pos;
+                }
+            }
         }
     }
 

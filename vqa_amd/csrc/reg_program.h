@@ -143,6 +143,15 @@ struct ParamInfo {
     int32_t ref_begin, ref_count;  // into refs[]
     int32_t resume_diag;           // first D-stage whose tables change; -1: restart from |0...0>
     int32_t resume_pc;             // phase to resume at, starting with its diagonal stage (0 when restarting)
+    // A parameter that drives one rotation of ONE fused 2x2 (U-stage u, D-stage u behind it) can also resume
+    // BEHIND that U-stage: with M the unshifted 2x2 and M' the one with the generator inserted, the state
+    // behind the stage is M' M^-1 applied to the unshifted one there (the other qubits' 2x2s commute with it),
+    // so the run loads the checkpoint in front of D-stage u, applies that one-qubit correction and goes on
+    // with the unshifted tables: one U-stage and one D-stage less per run, nothing to patch.
+    int32_t late_diag;             // that D-stage, -1: not available (several references, last U-stage, qubit on a wave bit there)
+    int32_t late_pc;               // the phase that applies it
+    int32_t late_mask;             // 1 << (position of the qubit in the layout of that D-stage)
+    int32_t pad;
 };
 
 // One run of a parameter-shift sweep besides the unshifted one.  variant 0: the
@@ -155,14 +164,14 @@ struct RunInfo {
 // What a sweep workgroup needs for one run, worked out per sample (device side,
 // 8 x 16 bytes): the patched table entries, the measurement mode and where to resume.
 struct RunRec {
-    double m[2];      // new rotation data of the fused 2x2 (table slot ids[0])
-    double fb[2];     // factor for the phase slot ids[1] (in front of the 2x2, or the parameter's own slot)
-    double fa[2];     // factor for the phase slot ids[2] (behind the 2x2)
+    double m[2];      // new rotation data of the fused 2x2 (table slot ids[0]);  late resumption: C00
+    double fb[2];     // factor for the phase slot ids[1] (in front of the 2x2, or the parameter's own slot);  late: C01
+    double fa[2];     // factor for the phase slot ids[2] (behind the 2x2);  late: C10
     double rho[2];    // pair: ratio of the unit factors left out of the two runs
     double cs[2];     // pair: cos, sin of half the shift of the rotation angle
-    int32_t ids[4];   // table slots (index into the workgroup's tables, -1: none); ids[3] unused
+    int32_t ids[4];   // table slots (index into the workgroup's tables, -1: none); ids[3]: late resumption: ParamInfo::late_mask, else 0
     int32_t out[4];   // mode (0: one value, 1: pair), output instance k, resume diagonal stage, resume phase
-    double pad[2];
+    double c11[2];    // late resumption: C11 (C = the one-qubit correction, in the frame of the checkpoint)
 };
 
 struct RegHeader {
