@@ -1195,9 +1195,37 @@ __device__ __forceinline__ void apply_clane(double2 (&amp)[kRegAmps], double2 c0
         clane_inplace(amp[r].x, amp[r].y, px, py, csx, csy, cox, coy);
     }
 }
+// Wave bit WB (thread bit 6 + WB): the partner amplitudes belong to another wave and come through the
+// transposition buffer, half of the state at a time (slot = [amplitude][thread]: no bank conflicts either way).
+// Every thread of the workgroup takes part.
+template <int WB>
+__device__ __forceinline__ void apply_cwave(double2 (&amp)[kRegAmps], double2 c00, double2 c01, double2 c10, double2 c11,
+                                            char* xbuf, int tid, int nthr) {
+    const bool up = (tid >> (6 + WB)) & 1;
+    const double csx = up ? c11.x : c00.x, csy = up ? c11.y : c00.y, cox = up ? c10.x : c01.x, coy = up ? c10.y : c01.y;
+    double2* buf = (double2*)xbuf;
+    const int partner = tid ^ (64 << WB);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int r = 0; r < kRegAmps / 2; ++r) buf[r * nthr + tid] = amp[r + 8 * half];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < kRegAmps / 2; ++r) {
+            const double2 p = buf[r * nthr + partner];
+            clane_inplace(amp[r + 8 * half].x, amp[r + 8 * half].y, p.x, p.y, csx, csy, cox, coy);
+        }
+        __syncthreads();
+    }
+}
 // mask = 1 << position (one bit per alternative, tested one after the other: each block updates the amplitudes in place)
-__device__ __forceinline__ void apply_correction(double2 (&amp)[kRegAmps], const double2* rec, int mask, int lane) {
+__device__ __forceinline__ void apply_correction(double2 (&amp)[kRegAmps], const double2* rec, int mask, const Ctx& cx) {
     const double2 c00 = rec[0], c01 = rec[1], c10 = rec[2], c11 = rec[7];
+    const int lane = cx.lane();
+    if (mask & (1 << 10)) apply_cwave<0>(amp, c00, c01, c10, c11, cx.xbuf, cx.tid(), cx.nthr);
+    if (mask & (1 << 11)) apply_cwave<1>(amp, c00, c01, c10, c11, cx.xbuf, cx.tid(), cx.nthr);
+    if (mask & (1 << 12)) apply_cwave<2>(amp, c00, c01, c10, c11, cx.xbuf, cx.tid(), cx.nthr);
+    if (mask & (1 << 13)) apply_cwave<3>(amp, c00, c01, c10, c11, cx.xbuf, cx.tid(), cx.nthr);
     if (mask & 1) apply_creg<0>(amp, c00, c01, c10, c11);
     if (mask & 2) apply_creg<1>(amp, c00, c01, c10, c11);
     if (mask & 4) apply_creg<2>(amp, c00, c01, c10, c11);
@@ -1440,7 +1468,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : BLOCK == 512 ? 2 : BLOCK
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             // late resumption: the checkpoint is the unshifted state behind the parameter's U-stage; the
             // run's state there differs by a 2x2 on the one qubit (the record is not replaced before the end of the run)
-            if (late) apply_correction(amp, pz, late, cx.lane());
+            if (late) apply_correction(amp, pz, late, cx);
             VQA_STAMP(1)
             // the next run's record travels while this run computes
             if (ri + 1 < NL && (tid & 63) < 8) nx = recs[(size_t)live[ri + 1] * 8 + (tid & 63)];

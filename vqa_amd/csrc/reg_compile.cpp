@@ -549,7 +549,8 @@ bool reg_compile(int n, int n_theta, const std::vector<vqa_op>& gate_list, RegPr
         for (int u = 0; u + 1 < NU; ++u) {
             for (auto& kv : uidx[u]) {
                 const int pos = dlayout[u].pos_of[kv.first];
-                if (pos >= R + L) continue;   // a wave bit: no partner within the wave
+                // (a wave bit: the partner amplitudes come through the transposition buffer, when the program has one)
+                if (pos >= R + L && P.n_xpose == 0) continue;
                 for (int i = 0; i < n_theta; ++i) {
                     ParamInfo& pi = P.params[i];
                     if (pi.ref_count != 1) continue;

@@ -148,7 +148,7 @@ struct ParamInfo {
     // behind the stage is M' M^-1 applied to the unshifted one there (the other qubits' 2x2s commute with it),
     // so the run loads the checkpoint in front of D-stage u, applies that one-qubit correction and goes on
     // with the unshifted tables: one U-stage and one D-stage less per run, nothing to patch.
-    int32_t late_diag;             // that D-stage, -1: not available (several references, last U-stage, qubit on a wave bit there)
+    int32_t late_diag;             // that D-stage, -1: not available (several references, last U-stage)
     int32_t late_pc;               // the phase that applies it
     int32_t late_mask;             // 1 << (position of the qubit in the layout of that D-stage)
     int32_t pad;
