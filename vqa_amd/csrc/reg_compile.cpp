@@ -14,6 +14,8 @@
 #include <string>
 #include <utility>
 
+#include <stdio.h>
+
 #include "reg_program.h"
 
 namespace vqa {
@@ -594,6 +596,9 @@ bool reg_compile(int n, int n_theta, const std::vector<vqa_op>& gate_list, RegPr
     H.n_refs = (int)P.refs.size();
     H.n_phases = (int)P.phases.size();
     H.has_xpose = P.n_xpose > 0;
+    if (getenv("VQA_PLAN_DEBUG"))
+        fprintf(stderr, "[vqa] register program: %d qubits, %d U-stages, %d phases, %d transpositions (%d distinct), %d sign tables\n",
+                n, NU, H.n_phases, P.n_xpose, H.n_xdesc, H.n_sign);
 
     const size_t tab1 = ((size_t)H.n_uent + H.n_d1 + H.n_d2) * 16;
     const size_t xbuf = H.has_xpose ? ((size_t)8 << n) : 0;  // half of the state at a time
