@@ -663,12 +663,22 @@ __device__ __forceinline__ void do_diag(double2 (&amp)[kRegAmps], const Prog& pp
     const auto* dd = &ddl;
     const double2* p1 = cx.ph1 + dd->ph1_base;
     const int t = cx.t();
+    // CZ / Z signs: sign(r, t) = base(t) ^ XOR_j (r_j & cross_j(t)) ^ rr(r).  The thread's bits (base, cross_0..3)
+    // go into the table below -- base flips the thread-only factor, cross_j the step of register bit j --
+    // and cost ten sign flips; rr is the same for every thread and is applied at the end, when there is one
+    const int sign_id = dd->sign_id;
+    unsigned sm = 0, rr = 0;
+    if (sign_id >= 0) {
+        sm = cx.smask[sign_id * cx.nthr + cx.tid()];
+        rr = pp.signs[sign_id].rr_par;
+    }
     // thread-only factor
     cplx F = { 1.0, 0.0 };
     for (int i = 0; i < cx.T; ++i) {
         const double2 p = p1[kRegBits + i];
         F = cmul(F, csel_conj({ p.x, p.y }, (unsigned)(t >> i) & 1u));
     }
+    F = { flip_if(F.x, sm & 1u), flip_if(F.y, sm & 1u) };
     const int tt_begin = dd->tt_begin, tt_count = dd->tt_count;
     for (int k = 0; k < tt_count; ++k) {
         const int pa = pp.pairs[tt_begin + k].a, pb = pp.pairs[tt_begin + k].b;
@@ -698,27 +708,29 @@ __device__ __forceinline__ void do_diag(double2 (&amp)[kRegAmps], const Prog& pp
 #pragma unroll
     for (int j = 0; j < kRegBits - 1; ++j) {
         const cplx cj = cconj(pj[j]);
-        const cplx w = cmul(cj, cj);
+        const cplx w0 = cmul(cj, cj);
+        const unsigned cr = (sm >> (1 + j)) & 1u;
+        const cplx w = { flip_if(w0.x, cr), flip_if(w0.y, cr) };
 #pragma unroll
         for (int r = 0; r < (1 << j); ++r) tb[r | (1 << j)] = cmul(tb[r], w);
     }
     const cplx c3 = cconj(pj[kRegBits - 1]);
-    const cplx w3 = cmul(c3, c3);
-    // CZ / Z signs: bit r of the thread's mask flips entry r
-    const int sign_id = dd->sign_id;
-    unsigned sm = 0;
-    if (sign_id >= 0) sm = cx.smask[sign_id * cx.nthr + cx.tid()];
+    const cplx w30 = cmul(c3, c3);
+    const unsigned cr3 = (sm >> kRegBits) & 1u;
+    const cplx w3 = { flip_if(w30.x, cr3), flip_if(w30.y, cr3) };
 #pragma unroll
     for (int r = 0; r < kRegAmps / 2; ++r) {
-        const int flip_lo = (int)((sm << (31 - r)) & 0x80000000u);
-        const int flip_hi = (int)((sm << (31 - (r + 8))) & 0x80000000u);
         const cplx hi = cmul(tb[r], w3);
-        cmul_inplace(amp[r].x, amp[r].y,
-                     __hiloint2double(__double2hiint(tb[r].x) ^ flip_lo, __double2loint(tb[r].x)),
-                     __hiloint2double(__double2hiint(tb[r].y) ^ flip_lo, __double2loint(tb[r].y)));
-        cmul_inplace(amp[r + 8].x, amp[r + 8].y,
-                     __hiloint2double(__double2hiint(hi.x) ^ flip_hi, __double2loint(hi.x)),
-                     __hiloint2double(__double2hiint(hi.y) ^ flip_hi, __double2loint(hi.y)));
+        cmul_inplace(amp[r].x, amp[r].y, tb[r].x, tb[r].y);
+        cmul_inplace(amp[r + 8].x, amp[r + 8].y, hi.x, hi.y);
+    }
+    if (rr) {
+        // signs between register bits: a uniform +-1 per amplitude
+#pragma unroll
+        for (int r = 0; r < kRegAmps; ++r) {
+            const double sg = ((rr >> r) & 1u) ? -1.0 : 1.0;
+            asm("v_mul_f64 %0, %0, %2\n\tv_mul_f64 %1, %1, %2" : "+v"(amp[r].x), "+v"(amp[r].y) : "s"(sg));
+        }
     }
     // register-register ZZ phases
     const int rr_begin = dd->rr_begin, rr_count = dd->rr_count;
@@ -1055,16 +1067,11 @@ __device__ __forceinline__ void thread_constants(const Prog& pp, unsigned short*
         unsigned c[kRegBits];
 #pragma unroll
         for (int j = 0; j < kRegBits; ++j) c[j] = (pp.signs[sg].cross[j][wi] >> bi) & 1u;
-        const unsigned rr = pp.signs[sg].rr_par;
-        unsigned m = 0;
+        // bit 0: the thread's own parity; bit 1 + j: the flip that register bit j brings (the signs between
+        // register bits, rr_par, are the same for every thread and are read where they are applied)
+        unsigned m = base;
 #pragma unroll
-        for (int r = 0; r < kRegAmps; ++r) {
-            unsigned s = base ^ ((rr >> r) & 1u);
-#pragma unroll
-            for (int j = 0; j < kRegBits; ++j)
-                if (r & (1 << j)) s ^= c[j];
-            m |= s << r;
-        }
+        for (int j = 0; j < kRegBits; ++j) m |= c[j] << (1 + j);
         smask[sg * BLOCK + tid] = (unsigned short)m;
     }
 }

@@ -251,12 +251,16 @@ bool reg_compile(int n, int n_theta, const std::vector<vqa_op>& gate_list, RegPr
     }
 
     // ---- schedule: ops + the layout every D-stage is applied in ----
+    // (run twice: dry, for every candidate of the initial layout, to see the layouts the diagonal stages
+    // would get; then for the chosen one)
     Layout lay;
-    for (int p = 0; p < kMaxPos; ++p) { lay.q_at[p] = p < n ? p : -1; lay.pos_of[p] = p; }
     std::vector<Layout> dlayout(ND);
-    auto emit = [&](int kind, int a, int b) { P.ops.push_back(RegOp{ kind, a, b, 0 }); };
+    bool dry = false;
+    bool sched_failed = false;
+    auto emit = [&](int kind, int a, int b) { if (!dry) P.ops.push_back(RegOp{ kind, a, b, 0 }); };
     auto emit_direct = [&](int q, int ue) {
         const int p = lay.pos_of[q];
+        if (dry) return;
         // 1: rotated through DPP partner fetches; 2: lane bits 4 / 5, rotated by the matrix unit
         P.uent[ue].on_lane = p < R ? 0 : (p - R >= 4 ? 2 : 1);
         if (p < R) emit(ROP_UREG, p, ue);
@@ -286,6 +290,7 @@ bool reg_compile(int n, int n_theta, const std::vector<vqa_op>& gate_list, RegPr
     const int slots_mfma[6] = { 0, 1, 2, R + 4, R + 5, -1 };
     const int* cheap_slots = mfma_pair ? slots_mfma : slots_dpp;
 
+    auto run_schedule = [&]() {
     for (int u = 0; u < NU; ++u) {
         std::vector<std::pair<int, int>> byq;  // (position, qubit)
         for (auto& kv : uidx[u]) byq.push_back({ lay.pos_of[kv.first], kv.first });
@@ -326,6 +331,10 @@ bool reg_compile(int n, int n_theta, const std::vector<vqa_op>& gate_list, RegPr
                     lay.q_at[pa] = qb; lay.pos_of[qb] = pa;
                     lay.q_at[pb] = qa; lay.pos_of[qa] = pb;
                 }
+                if (dry) {
+                    remaining.erase(remaining.begin(), remaining.begin() + nb);
+                    continue;
+                }
                 int sigma[kMaxPos];
                 for (int p = 0; p < n; ++p) sigma[p] = old_pos_of[lay.q_at[p]];
                 std::vector<uint32_t> f = find_swizzle(n, sigma);
@@ -339,12 +348,14 @@ bool reg_compile(int n, int n_theta, const std::vector<vqa_op>& gate_list, RegPr
                 for (int p = 0; p < n; ++p) xd.rconst[p] = xd.wconst[sigma[p]];
                 if (sigma[R - 1] != R - 1 || xd.wconst[R - 1] != (16 << (n - 1))) {
                     *why = "internal: transposition does not split into halves";
-                    return false;
+                    sched_failed = true;
+                    return;
                 }
                 for (int p = 0; p < n; ++p)
                     if (p != R - 1 && (xd.wconst[p] & (16 << (n - 1)))) {
                         *why = "internal: transposition slot function mixes the halves";
-                        return false;
+                        sched_failed = true;
+                        return;
                     }
                 int xid = -1;
                 for (size_t k = 0; k < P.xdesc.size() && xid < 0; ++k)
@@ -359,9 +370,78 @@ bool reg_compile(int n, int n_theta, const std::vector<vqa_op>& gate_list, RegPr
         if (u < NU - 1) {
             dlayout[u] = lay;
             emit(ROP_DIAG, u, 0);
-            ++P.n_diag;
+            if (!dry) ++P.n_diag;
         }
     }
+    };
+    // The initial layout (which qubit starts at which position) is free: |0...0> looks the same in all of
+    // them.  A diagonal stage is cheapest when no CZ / Z sign and no ZZ phase sits between two register
+    // bits (see do_diag): the identity, the strides coprime to n and a few shuffles are tried dry, and the
+    // one whose diagonal stages cost least is taken (first best: the identity when nothing is gained).
+    auto stage_cost = [&]() {
+        int cost = 0;
+        for (int d = 0; d < ND; ++d) {
+            const Stage& sd = st[dstages[d]];
+            const Layout& ly = dlayout[d];
+            bool rr = false;
+            for (auto& pq : sd.cz) rr |= ly.pos_of[pq.first] < R && ly.pos_of[pq.second] < R;
+            for (int q : sd.z) rr |= ly.pos_of[q] < R;
+            cost += rr ? 2 : 0;
+            for (auto& kv : sd.zz) {
+                const bool a = ly.pos_of[kv.first.first] < R, b = ly.pos_of[kv.first.second] < R;
+                cost += (a && b) ? 4 : (a || b) ? 1 : 0;
+            }
+        }
+        return cost;
+    };
+    std::vector<std::vector<int>> candidates;
+    {
+        std::vector<int> id(n);
+        for (int p = 0; p < n; ++p) id[p] = p;
+        candidates.push_back(id);
+        if (n > R) {
+            for (int s = 2; s < n; ++s) {
+                int g = s, h = n;
+                while (h) { const int t = g % h; g = h; h = t; }
+                if (g != 1) continue;
+                std::vector<int> c(n);
+                for (int p = 0; p < n; ++p) c[p] = (p * s) % n;
+                candidates.push_back(c);
+            }
+            uint64_t rng = 0x9E3779B97F4A7C15ull;
+            for (int k = 0; k < 24; ++k) {
+                std::vector<int> c = id;
+                for (int p = n - 1; p > 0; --p) {
+                    rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+                    std::swap(c[p], c[(int)((rng >> 33) % (uint64_t)(p + 1))]);
+                }
+                candidates.push_back(c);
+            }
+        }
+    }
+    auto set_layout = [&](const std::vector<int>& c) {
+        for (int p = 0; p < kMaxPos; ++p) { lay.q_at[p] = p < n ? c[p] : -1; lay.pos_of[p] = p; }
+        for (int p = 0; p < n; ++p) lay.pos_of[c[p]] = p;
+    };
+    size_t best = 0;
+    if (candidates.size() > 1 && !getenv("VQA_REG_NO_LAYOUT_SEARCH")) {
+        int best_cost = 1 << 30;
+        dry = true;
+        for (size_t k = 0; k < candidates.size(); ++k) {
+            set_layout(candidates[k]);
+            run_schedule();
+            const int c = stage_cost();
+            if (c < best_cost) { best_cost = c; best = k; }
+            if (c == 0) break;
+        }
+        dry = false;
+    }
+    set_layout(candidates[best]);
+    run_schedule();
+    if (sched_failed) return false;
+    if (getenv("VQA_PLAN_DEBUG"))
+        fprintf(stderr, "[vqa] register program: initial layout number %zu of %zu, diagonal-stage cost %d\n", best,
+                candidates.size(), stage_cost());
     emit(ROP_END, 0, 0);
     for (int p = 0; p < kMaxPos; ++p) H.final_qubit_at_pos[p] = (int8_t)(p < n ? lay.q_at[p] : -1);
 
