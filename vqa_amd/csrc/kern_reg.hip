@@ -595,6 +595,9 @@ struct Ctx {
     const double2* ph2;
     char* xbuf;           // LDS transposition buffer
     const unsigned short* smask;  // LDS: [sign table][thread] 16-bit sign masks
+    // LDS (sweep kernel, may be null): per diagonal stage the thread-only phase factor in two tables, one by the
+    // low half of the thread bits and one by the high half; valid while no phase slot is patched
+    const double2* ftab;
     int T, nthr;
     int wave, tmask;   // uniform: wave of the workgroup, (1 << T) - 1
     // Thread ids are worked out where they are needed (two instructions) instead of
@@ -652,7 +655,7 @@ __device__ __forceinline__ void do_xpose(double2 (&amp)[kRegAmps], const Prog& p
 }
 
 // One diagonal stage (descriptor did).
-__device__ __forceinline__ void do_diag(double2 (&amp)[kRegAmps], const Prog& pp, const Ctx& cx, int did) {
+__device__ __forceinline__ void do_diag(double2 (&amp)[kRegAmps], const Prog& pp, const Ctx& cx, int did, bool use_ftab) {
     // the whole descriptor in one go (field by field each scalar load is waited for where it is used)
     static_assert(sizeof(DDesc) == 48, "DDesc is fetched as three 16-byte scalar loads");
     const VQA_CAS i32x4* ddv = (const VQA_CAS i32x4*)(pp.ddesc + did);
@@ -672,14 +675,21 @@ __device__ __forceinline__ void do_diag(double2 (&amp)[kRegAmps], const Prog& pp
         sm = cx.smask[sign_id * cx.nthr + cx.tid()];
         rr = pp.signs[sign_id].rr_par;
     }
-    // thread-only factor
+    // thread-only factor: from the stage's two tables, or bit by bit
+    const int tt_begin = dd->tt_begin, tt_count = dd->tt_count;
     cplx F = { 1.0, 0.0 };
-    for (int i = 0; i < cx.T; ++i) {
-        const double2 p = p1[kRegBits + i];
-        F = cmul(F, csel_conj({ p.x, p.y }, (unsigned)(t >> i) & 1u));
+    if (use_ftab) {
+        const int TL = cx.T >> 1;
+        const double2* ft = cx.ftab + (size_t)did * ((1 << TL) + (1 << (cx.T - TL)));
+        const double2 fa = ft[t & ((1 << TL) - 1)], fb = ft[(1 << TL) + (t >> TL)];
+        F = cmul({ fa.x, fa.y }, { fb.x, fb.y });
+    } else {
+        for (int i = 0; i < cx.T; ++i) {
+            const double2 p = p1[kRegBits + i];
+            F = cmul(F, csel_conj({ p.x, p.y }, (unsigned)(t >> i) & 1u));
+        }
     }
     F = { flip_if(F.x, sm & 1u), flip_if(F.y, sm & 1u) };
-    const int tt_begin = dd->tt_begin, tt_count = dd->tt_count;
     for (int k = 0; k < tt_count; ++k) {
         const int pa = pp.pairs[tt_begin + k].a, pb = pp.pairs[tt_begin + k].b;
         const double2 z = cx.ph2[pp.pairs[tt_begin + k].ph2];
@@ -751,7 +761,7 @@ __device__ __forceinline__ void do_diag(double2 (&amp)[kRegAmps], const Prog& pp
 // the workgroup's area.
 template <bool SCALED>
 __device__ __forceinline__ void run_phases(double2 (&amp)[kRegAmps], const Prog& pp, Ctx& cx, int p0,
-                                           bool diag_only_first, bool ckpt) {
+                                           bool diag_only_first, bool ckpt, bool use_ftab = false) {
     const VQA_CAS PhaseOp* ph = pp.phases;
     int first_mask = diag_only_first ? (PH_DIAG | PH_END) : -1;
     VQA_STAMP0
@@ -804,7 +814,7 @@ __device__ __forceinline__ void run_phases(double2 (&amp)[kRegAmps], const Prog&
         if (flags & PH_DIAG) {
             const int did = d0.z;
             if (ckpt) store_state(amp, cx.area, (unsigned)did * cx.image_bytes, cx.nthr, cx.tid());
-            do_diag(amp, pp, cx, did);
+            do_diag(amp, pp, cx, did, use_ftab);
         }
         VQA_STAMP(13)
     }
@@ -1103,6 +1113,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : BLOCK == 512 ? 2 : VQA_W
     cx.ph2 = cx.ph1 + N1;
     cx.xbuf = (char*)xbuf;
     cx.smask = smask;
+    cx.ftab = nullptr;
     cx.T = T; cx.nthr = BLOCK;
     cx.wave = __builtin_amdgcn_readfirstlane(tid >> 6); cx.tmask = (1 << T) - 1;
     cx.xc_id = -1; cx.xc_wt = 0; cx.xc_rt = 0;
@@ -1366,11 +1377,14 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : BLOCK == 512 ? 2 : BLOCK
     double2* sav = pz + 8;                                // what the current patch replaced (3 entries, thread 0's)
     double* basev = (double*)(pz + 16);                   // the unshifted values (79 entries), squared norm of psi
     unsigned short* smask = (unsigned short*)(basev + 80);
+    constexpr int TL = T >> 1, FE = (1 << TL) + (1 << (T - TL));   // entries of a stage's two thread-factor tables
+    double2* ftab = (double2*)((char*)smask + (((size_t)pp.H->n_sign * BLOCK * 2 + 15) & ~(size_t)15));   // ND * FE
 
     Ctx cx;
     cx.mat = tabs; cx.ph1 = tabs + NU; cx.ph2 = tabs + NU + N1;
     cx.xbuf = (char*)xbuf;
     cx.smask = smask;
+    cx.ftab = ftab;
     cx.T = T; cx.nthr = BLOCK;
     cx.wave = __builtin_amdgcn_readfirstlane(tid >> 6); cx.tmask = (1 << T) - 1;
     cx.xc_id = -1; cx.xc_wt = 0; cx.xc_rt = 0;
@@ -1418,6 +1432,20 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : BLOCK == 512 ? 2 : BLOCK
         for (int r = tid; r < NR; r += BLOCK)
             make_run_record<BLOCK, true, true>(a, pp, r, row, NU, N1, a.recs + (size_t)blockIdx.x * NR + r);
         __threadfence_block();
+        // the thread-only factors of the diagonal stages, by halves of the thread bits (unpatched tables)
+        __syncthreads();
+        for (int i = tid; i < ND * FE; i += BLOCK) {
+            const int d = i / FE, e = i - d * FE;
+            const bool high = e >= (1 << TL);
+            const int bits = high ? e - (1 << TL) : e, b0 = high ? TL : 0, nb = high ? T - TL : TL;
+            const double2* p1 = cx.ph1 + pp.ddesc[d].ph1_base + kRegBits + b0;
+            cplx f = { 1.0, 0.0 };
+            for (int k = 0; k < nb; ++k) {
+                const double2 p = p1[k];
+                f = cmul(f, csel_conj({ p.x, p.y }, (unsigned)(bits >> k) & 1u));
+            }
+            ftab[i] = make_double2(f.x, f.y);
+        }
         VQA_STAMP(0)
 
         // run -1 is the unshifted circuit; thread 0 keeps what the current patch replaced
@@ -1479,7 +1507,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : BLOCK == 512 ? 2 : BLOCK
             VQA_STAMP(1)
             // the next run's record travels while this run computes
             if (ri + 1 < NL && (tid & 63) < 8) nx = recs[(size_t)live[ri + 1] * 8 + (tid & 63)];
-            if (!VQA_ABL(a, 8)) run_phases<true>(amp, pp, cx, pc0, rdiag >= 0, r < 0);
+            // (a run that patches a phase slot works the thread-only factors out bit by bit)
+            if (!VQA_ABL(a, 8)) run_phases<true>(amp, pp, cx, pc0, rdiag >= 0, r < 0, id_b < 0 && id_a < 0);
             VQA_STAMP(2)
             if (r < 0) store_state(amp, cx.area, (unsigned)ND * cx.image_bytes, BLOCK, tid);
             if (!VQA_ABL(a, 4)) {
@@ -1589,6 +1618,7 @@ __global__ __launch_bounds__(64, VQA_GROUP_WAVES) void k_reg_group(RegArgs a) {
     cx.ph2 = cx.ph1 + N1;
     cx.xbuf = (char*)xbuf;
     cx.smask = smask;
+    cx.ftab = nullptr;
     cx.T = T; cx.nthr = BLOCK;
     cx.wave = 0; cx.tmask = (1 << T) - 1;
     cx.xc_id = -1; cx.xc_wt = 0; cx.xc_rt = 0;
