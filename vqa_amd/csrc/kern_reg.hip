@@ -675,59 +675,70 @@ __device__ __forceinline__ void do_diag(double2 (&amp)[kRegAmps], const Prog& pp
         sm = cx.smask[sign_id * cx.nthr + cx.tid()];
         rr = pp.signs[sign_id].rr_par;
     }
-    // thread-only factor: from the stage's two tables, or bit by bit
+    // The first table entry (thread-only factor times the register bits' phases) and the step of each register
+    // bit, conj(p_j)^2: from the stage's tables (the thread-only factor in two halves, the low one with the
+    // register bits' phases folded in, and the four steps), or worked out bit by bit when a slot is patched
+    // or a ZZ phase between a register and a thread bit makes the steps differ from thread to thread
     const int tt_begin = dd->tt_begin, tt_count = dd->tt_count;
-    cplx F = { 1.0, 0.0 };
-    if (use_ftab) {
-        const int TL = cx.T >> 1;
-        const double2* ft = cx.ftab + (size_t)did * ((1 << TL) + (1 << (cx.T - TL)));
+    const int rt_begin = dd->rt_begin, rt_count = dd->rt_count;
+    cplx T0, wq[kRegBits];
+    if (use_ftab && rt_count == 0) {
+        const int TL = cx.T >> 1, FE = (1 << TL) + (1 << (cx.T - TL));
+        const double2* ft = cx.ftab + (size_t)did * (FE + kRegBits);
         const double2 fa = ft[t & ((1 << TL) - 1)], fb = ft[(1 << TL) + (t >> TL)];
-        F = cmul({ fa.x, fa.y }, { fb.x, fb.y });
+        T0 = cmul({ fa.x, fa.y }, { fb.x, fb.y });
+#pragma unroll
+        for (int j = 0; j < kRegBits; ++j) {
+            const double2 w = ft[FE + j];
+            wq[j] = { w.x, w.y };
+        }
     } else {
+        cplx F = { 1.0, 0.0 };
         for (int i = 0; i < cx.T; ++i) {
             const double2 p = p1[kRegBits + i];
             F = cmul(F, csel_conj({ p.x, p.y }, (unsigned)(t >> i) & 1u));
         }
+        // effective phase of each register bit
+        cplx pj[kRegBits];
+#pragma unroll
+        for (int j = 0; j < kRegBits; ++j) {
+            const double2 p = p1[j];
+            pj[j] = { p.x, p.y };
+        }
+        for (int k = 0; k < rt_count; ++k) {
+            const int pa = pp.pairs[rt_begin + k].a, pb = pp.pairs[rt_begin + k].b;
+            const double2 z = cx.ph2[pp.pairs[rt_begin + k].ph2];
+            const cplx ze = csel_conj({ z.x, z.y }, (unsigned)(t >> pb) & 1u);
+#pragma unroll
+            for (int j = 0; j < kRegBits; ++j)
+                if (pa == j) pj[j] = cmul(pj[j], ze);
+        }
+        T0 = cmul(cmul(F, cmul(pj[0], pj[1])), cmul(pj[2], pj[3]));
+#pragma unroll
+        for (int j = 0; j < kRegBits; ++j) {
+            const cplx cj = cconj(pj[j]);
+            wq[j] = cmul(cj, cj);
+        }
     }
-    F = { flip_if(F.x, sm & 1u), flip_if(F.y, sm & 1u) };
+    T0 = { flip_if(T0.x, sm & 1u), flip_if(T0.y, sm & 1u) };
     for (int k = 0; k < tt_count; ++k) {
         const int pa = pp.pairs[tt_begin + k].a, pb = pp.pairs[tt_begin + k].b;
         const double2 z = cx.ph2[pp.pairs[tt_begin + k].ph2];
-        F = cmul(F, csel_conj({ z.x, z.y }, (unsigned)((t >> pa) ^ (t >> pb)) & 1u));
-    }
-    // effective phase of each register bit
-    cplx pj[kRegBits];
-#pragma unroll
-    for (int j = 0; j < kRegBits; ++j) {
-        const double2 p = p1[j];
-        pj[j] = { p.x, p.y };
-    }
-    const int rt_begin = dd->rt_begin, rt_count = dd->rt_count;
-    for (int k = 0; k < rt_count; ++k) {
-        const int pa = pp.pairs[rt_begin + k].a, pb = pp.pairs[rt_begin + k].b;
-        const double2 z = cx.ph2[pp.pairs[rt_begin + k].ph2];
-        const cplx ze = csel_conj({ z.x, z.y }, (unsigned)(t >> pb) & 1u);
-#pragma unroll
-        for (int j = 0; j < kRegBits; ++j)
-            if (pa == j) pj[j] = cmul(pj[j], ze);
+        T0 = cmul(T0, csel_conj({ z.x, z.y }, (unsigned)((t >> pa) ^ (t >> pb)) & 1u));
     }
     // phase table by doubling, T[r | 1<<j] = T[r] * conj(pj)^2: the lower 8 entries
     // are kept, the upper 8 are formed on the fly to save registers
     cplx tb[kRegAmps / 2];
-    tb[0] = cmul(cmul(F, cmul(pj[0], pj[1])), cmul(pj[2], pj[3]));
+    tb[0] = T0;
 #pragma unroll
     for (int j = 0; j < kRegBits - 1; ++j) {
-        const cplx cj = cconj(pj[j]);
-        const cplx w0 = cmul(cj, cj);
         const unsigned cr = (sm >> (1 + j)) & 1u;
-        const cplx w = { flip_if(w0.x, cr), flip_if(w0.y, cr) };
+        const cplx w = { flip_if(wq[j].x, cr), flip_if(wq[j].y, cr) };
 #pragma unroll
         for (int r = 0; r < (1 << j); ++r) tb[r | (1 << j)] = cmul(tb[r], w);
     }
-    const cplx c3 = cconj(pj[kRegBits - 1]);
-    const cplx w30 = cmul(c3, c3);
     const unsigned cr3 = (sm >> kRegBits) & 1u;
-    const cplx w3 = { flip_if(w30.x, cr3), flip_if(w30.y, cr3) };
+    const cplx w3 = { flip_if(wq[kRegBits - 1].x, cr3), flip_if(wq[kRegBits - 1].y, cr3) };
 #pragma unroll
     for (int r = 0; r < kRegAmps / 2; ++r) {
         const cplx hi = cmul(tb[r], w3);
@@ -1378,7 +1389,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : BLOCK == 512 ? 2 : BLOCK
     double* basev = (double*)(pz + 16);                   // the unshifted values (79 entries), squared norm of psi
     unsigned short* smask = (unsigned short*)(basev + 80);
     constexpr int TL = T >> 1, FE = (1 << TL) + (1 << (T - TL));   // entries of a stage's two thread-factor tables
-    double2* ftab = (double2*)((char*)smask + (((size_t)pp.H->n_sign * BLOCK * 2 + 15) & ~(size_t)15));   // ND * FE
+    double2* ftab = (double2*)((char*)smask + (((size_t)pp.H->n_sign * BLOCK * 2 + 15) & ~(size_t)15));   // ND * (FE + kRegBits)
 
     Ctx cx;
     cx.mat = tabs; cx.ph1 = tabs + NU; cx.ph2 = tabs + NU + N1;
@@ -1434,15 +1445,29 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : BLOCK == 512 ? 2 : BLOCK
         __threadfence_block();
         // the thread-only factors of the diagonal stages, by halves of the thread bits (unpatched tables)
         __syncthreads();
-        for (int i = tid; i < ND * FE; i += BLOCK) {
-            const int d = i / FE, e = i - d * FE;
-            const bool high = e >= (1 << TL);
-            const int bits = high ? e - (1 << TL) : e, b0 = high ? TL : 0, nb = high ? T - TL : TL;
-            const double2* p1 = cx.ph1 + pp.ddesc[d].ph1_base + kRegBits + b0;
+        for (int i = tid; i < ND * (FE + kRegBits); i += BLOCK) {
+            const int d = i / (FE + kRegBits), e = i - d * (FE + kRegBits);
+            const double2* p1 = cx.ph1 + pp.ddesc[d].ph1_base;
             cplx f = { 1.0, 0.0 };
-            for (int k = 0; k < nb; ++k) {
-                const double2 p = p1[k];
-                f = cmul(f, csel_conj({ p.x, p.y }, (unsigned)(bits >> k) & 1u));
+            if (e >= FE) {
+                // the step of register bit e - FE
+                const double2 p = p1[e - FE];
+                const cplx cj = { p.x, -p.y };
+                f = cmul(cj, cj);
+            } else {
+                const bool high = e >= (1 << TL);
+                const int bits = high ? e - (1 << TL) : e, b0 = high ? TL : 0, nb = high ? T - TL : TL;
+                for (int k = 0; k < nb; ++k) {
+                    const double2 p = p1[kRegBits + b0 + k];
+                    f = cmul(f, csel_conj({ p.x, p.y }, (unsigned)(bits >> k) & 1u));
+                }
+                if (!high) {
+                    // the register bits' own phases (all bits clear) ride in the low table
+                    for (int j = 0; j < kRegBits; ++j) {
+                        const double2 p = p1[j];
+                        f = cmul(f, { p.x, p.y });
+                    }
+                }
             }
             ftab[i] = make_double2(f.x, f.y);
         }

@@ -688,7 +688,7 @@ bool reg_compile(int n, int n_theta, const std::vector<vqa_op>& gate_list, RegPr
     P.lds_bytes = (size_t)H.S * tab1 + xbuf + fixed + (size_t)H.n_uent * 48;
     // + run record, unshifted values, the diagonal stages' thread-factor tables (two per stage, by halves of the thread bits)
     P.lds_bytes_psr = tab1 + xbuf + fixed + 16 * 16 + 80 * sizeof(double) +
-                      (size_t)H.n_ddesc * ((1 << (T >> 1)) + (1 << (T - (T >> 1)))) * 16 + 16;
+                      (size_t)H.n_ddesc * ((1 << (T >> 1)) + (1 << (T - (T >> 1))) + kRegBits) * 16 + 16;
     // (64 bytes of margin for the kernels' few statically allocated words)
     if (std::max(P.lds_bytes, P.lds_bytes_psr) + 64 > 160 * 1024) { *why = "per-evaluation tables do not fit LDS"; return false; }
 
