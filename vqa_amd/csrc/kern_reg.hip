@@ -41,6 +41,9 @@ namespace vqa {
 // phase loop of shifted evaluations; 9: run the two shifts one by one instead of as a pair;
 // 10: pair measurement without loading the unshifted state; 11: without its reductions.
 // waves per SIMD the sweep kernel is register-budgeted for
+#ifndef VQA_EXP
+#define VQA_EXP 0
+#endif
 #ifndef VQA_WAVES
 #define VQA_WAVES 3
 #endif
@@ -654,6 +657,91 @@ __device__ __forceinline__ void do_xpose(double2 (&amp)[kRegAmps], const Prog& p
     }
 }
 
+// One diagonal stage, the form for the 1024-thread workgroups (128 registers per thread): the thread-only
+// factor bit by bit, the CZ / Z signs as one 16-bit mask per thread (bit r flips entry r).  The table form
+// below needs a few registers more, which there end up in scratch inside the phase loop.
+__device__ __forceinline__ void do_diag_masked(double2 (&amp)[kRegAmps], const Prog& pp, const Ctx& cx, int did) {
+    // the whole descriptor in one go (field by field each scalar load is waited for where it is used)
+    static_assert(sizeof(DDesc) == 48, "DDesc is fetched as three 16-byte scalar loads");
+    const VQA_CAS i32x4* ddv = (const VQA_CAS i32x4*)(pp.ddesc + did);
+    const i32x4 dd0 = ddv[0], dd1 = ddv[1], dd2 = ddv[2];
+    struct { int ph1_base, tt_begin, tt_count, rt_begin, rt_count, rr_begin, rr_count, sign_id; } ddl =
+        { dd0.x, dd0.y, dd0.z, dd0.w, dd1.x, dd1.y, dd1.z, dd1.w };
+    (void)dd2;
+    const auto* dd = &ddl;
+    const double2* p1 = cx.ph1 + dd->ph1_base;
+    const int t = cx.t();
+    // thread-only factor
+    cplx F = { 1.0, 0.0 };
+    for (int i = 0; i < cx.T; ++i) {
+        const double2 p = p1[kRegBits + i];
+        F = cmul(F, csel_conj({ p.x, p.y }, (unsigned)(t >> i) & 1u));
+    }
+    const int tt_begin = dd->tt_begin, tt_count = dd->tt_count;
+    for (int k = 0; k < tt_count; ++k) {
+        const int pa = pp.pairs[tt_begin + k].a, pb = pp.pairs[tt_begin + k].b;
+        const double2 z = cx.ph2[pp.pairs[tt_begin + k].ph2];
+        F = cmul(F, csel_conj({ z.x, z.y }, (unsigned)((t >> pa) ^ (t >> pb)) & 1u));
+    }
+    // effective phase of each register bit
+    cplx pj[kRegBits];
+#pragma unroll
+    for (int j = 0; j < kRegBits; ++j) {
+        const double2 p = p1[j];
+        pj[j] = { p.x, p.y };
+    }
+    const int rt_begin = dd->rt_begin, rt_count = dd->rt_count;
+    for (int k = 0; k < rt_count; ++k) {
+        const int pa = pp.pairs[rt_begin + k].a, pb = pp.pairs[rt_begin + k].b;
+        const double2 z = cx.ph2[pp.pairs[rt_begin + k].ph2];
+        const cplx ze = csel_conj({ z.x, z.y }, (unsigned)(t >> pb) & 1u);
+#pragma unroll
+        for (int j = 0; j < kRegBits; ++j)
+            if (pa == j) pj[j] = cmul(pj[j], ze);
+    }
+    // phase table by doubling, T[r | 1<<j] = T[r] * conj(pj)^2: the lower 8 entries
+    // are kept, the upper 8 are formed on the fly to save registers
+    cplx tb[kRegAmps / 2];
+    tb[0] = cmul(cmul(F, cmul(pj[0], pj[1])), cmul(pj[2], pj[3]));
+#pragma unroll
+    for (int j = 0; j < kRegBits - 1; ++j) {
+        const cplx cj = cconj(pj[j]);
+        const cplx w = cmul(cj, cj);
+#pragma unroll
+        for (int r = 0; r < (1 << j); ++r) tb[r | (1 << j)] = cmul(tb[r], w);
+    }
+    const cplx c3 = cconj(pj[kRegBits - 1]);
+    const cplx w3 = cmul(c3, c3);
+    // CZ / Z signs: bit r of the thread's mask flips entry r
+    const int sign_id = dd->sign_id;
+    unsigned sm = 0;
+    if (sign_id >= 0) sm = cx.smask[sign_id * cx.nthr + cx.tid()];
+#pragma unroll
+    for (int r = 0; r < kRegAmps / 2; ++r) {
+        const int flip_lo = (int)((sm << (31 - r)) & 0x80000000u);
+        const int flip_hi = (int)((sm << (31 - (r + 8))) & 0x80000000u);
+        const cplx hi = cmul(tb[r], w3);
+        cmul_inplace(amp[r].x, amp[r].y,
+                     __hiloint2double(__double2hiint(tb[r].x) ^ flip_lo, __double2loint(tb[r].x)),
+                     __hiloint2double(__double2hiint(tb[r].y) ^ flip_lo, __double2loint(tb[r].y)));
+        cmul_inplace(amp[r + 8].x, amp[r + 8].y,
+                     __hiloint2double(__double2hiint(hi.x) ^ flip_hi, __double2loint(hi.x)),
+                     __hiloint2double(__double2hiint(hi.y) ^ flip_hi, __double2loint(hi.y)));
+    }
+    // register-register ZZ phases
+    const int rr_begin = dd->rr_begin, rr_count = dd->rr_count;
+    for (int k = 0; k < rr_count; ++k) {
+        const int pa = pp.pairs[rr_begin + k].a, pb = pp.pairs[rr_begin + k].b;
+        const double2 z = cx.ph2[pp.pairs[rr_begin + k].ph2];
+#pragma unroll
+        for (int r = 0; r < kRegAmps; ++r) {
+            const cplx ze = csel_conj({ z.x, z.y }, (unsigned)((r >> pa) ^ (r >> pb)) & 1u);
+            cmul_inplace(amp[r].x, amp[r].y, ze.x, ze.y);
+        }
+    }
+}
+
+
 // One diagonal stage (descriptor did).
 __device__ __forceinline__ void do_diag(double2 (&amp)[kRegAmps], const Prog& pp, const Ctx& cx, int did, bool use_ftab) {
     // the whole descriptor in one go (field by field each scalar load is waited for where it is used)
@@ -681,17 +769,37 @@ __device__ __forceinline__ void do_diag(double2 (&amp)[kRegAmps], const Prog& pp
     // or a ZZ phase between a register and a thread bit makes the steps differ from thread to thread
     const int tt_begin = dd->tt_begin, tt_count = dd->tt_count;
     const int rt_begin = dd->rt_begin, rt_count = dd->rt_count;
-    cplx T0, wq[kRegBits];
+    // (two separate blocks up to the finished table: what is alive where they meet is the table alone)
+    cplx tb[kRegAmps / 2], w3;
+    auto step_of = [&](cplx w, int j) {   // the step of register bit j with the thread's flip
+        const unsigned cr = (sm >> (1 + j)) & 1u;
+        return cplx{ flip_if(w.x, cr), flip_if(w.y, cr) };
+    };
+    auto thread_pairs = [&](cplx T0) {    // ZZ phases between thread bits, the thread's own sign
+        T0 = { flip_if(T0.x, sm & 1u), flip_if(T0.y, sm & 1u) };
+        for (int k = 0; k < tt_count; ++k) {
+            const int pa = pp.pairs[tt_begin + k].a, pb = pp.pairs[tt_begin + k].b;
+            const double2 z = cx.ph2[pp.pairs[tt_begin + k].ph2];
+            T0 = cmul(T0, csel_conj({ z.x, z.y }, (unsigned)((t >> pa) ^ (t >> pb)) & 1u));
+        }
+        return T0;
+    };
     if (use_ftab && rt_count == 0) {
         const int TL = cx.T >> 1, FE = (1 << TL) + (1 << (cx.T - TL));
         const double2* ft = cx.ftab + (size_t)did * (FE + kRegBits);
         const double2 fa = ft[t & ((1 << TL) - 1)], fb = ft[(1 << TL) + (t >> TL)];
-        T0 = cmul({ fa.x, fa.y }, { fb.x, fb.y });
+        tb[0] = thread_pairs(cmul({ fa.x, fa.y }, { fb.x, fb.y }));
+        // phase table by doubling, T[r | 1<<j] = T[r] * conj(pj)^2: the lower 8 entries
+        // are kept, the upper 8 are formed on the fly to save registers
 #pragma unroll
-        for (int j = 0; j < kRegBits; ++j) {
-            const double2 w = ft[FE + j];
-            wq[j] = { w.x, w.y };
+        for (int j = 0; j < kRegBits - 1; ++j) {
+            const double2 wj = ft[FE + j];
+            const cplx w = step_of({ wj.x, wj.y }, j);
+#pragma unroll
+            for (int r = 0; r < (1 << j); ++r) tb[r | (1 << j)] = cmul(tb[r], w);
         }
+        const double2 wl = ft[FE + kRegBits - 1];
+        w3 = step_of({ wl.x, wl.y }, kRegBits - 1);
     } else {
         cplx F = { 1.0, 0.0 };
         for (int i = 0; i < cx.T; ++i) {
@@ -713,32 +821,17 @@ __device__ __forceinline__ void do_diag(double2 (&amp)[kRegAmps], const Prog& pp
             for (int j = 0; j < kRegBits; ++j)
                 if (pa == j) pj[j] = cmul(pj[j], ze);
         }
-        T0 = cmul(cmul(F, cmul(pj[0], pj[1])), cmul(pj[2], pj[3]));
+        tb[0] = thread_pairs(cmul(cmul(F, cmul(pj[0], pj[1])), cmul(pj[2], pj[3])));
 #pragma unroll
-        for (int j = 0; j < kRegBits; ++j) {
+        for (int j = 0; j < kRegBits - 1; ++j) {
             const cplx cj = cconj(pj[j]);
-            wq[j] = cmul(cj, cj);
+            const cplx w = step_of(cmul(cj, cj), j);
+#pragma unroll
+            for (int r = 0; r < (1 << j); ++r) tb[r | (1 << j)] = cmul(tb[r], w);
         }
+        const cplx c3 = cconj(pj[kRegBits - 1]);
+        w3 = step_of(cmul(c3, c3), kRegBits - 1);
     }
-    T0 = { flip_if(T0.x, sm & 1u), flip_if(T0.y, sm & 1u) };
-    for (int k = 0; k < tt_count; ++k) {
-        const int pa = pp.pairs[tt_begin + k].a, pb = pp.pairs[tt_begin + k].b;
-        const double2 z = cx.ph2[pp.pairs[tt_begin + k].ph2];
-        T0 = cmul(T0, csel_conj({ z.x, z.y }, (unsigned)((t >> pa) ^ (t >> pb)) & 1u));
-    }
-    // phase table by doubling, T[r | 1<<j] = T[r] * conj(pj)^2: the lower 8 entries
-    // are kept, the upper 8 are formed on the fly to save registers
-    cplx tb[kRegAmps / 2];
-    tb[0] = T0;
-#pragma unroll
-    for (int j = 0; j < kRegBits - 1; ++j) {
-        const unsigned cr = (sm >> (1 + j)) & 1u;
-        const cplx w = { flip_if(wq[j].x, cr), flip_if(wq[j].y, cr) };
-#pragma unroll
-        for (int r = 0; r < (1 << j); ++r) tb[r | (1 << j)] = cmul(tb[r], w);
-    }
-    const unsigned cr3 = (sm >> kRegBits) & 1u;
-    const cplx w3 = { flip_if(wq[kRegBits - 1].x, cr3), flip_if(wq[kRegBits - 1].y, cr3) };
 #pragma unroll
     for (int r = 0; r < kRegAmps / 2; ++r) {
         const cplx hi = cmul(tb[r], w3);
@@ -770,7 +863,7 @@ __device__ __forceinline__ void do_diag(double2 (&amp)[kRegAmps], const Prog& pp
 // diagonal stage (resuming from a checkpoint taken in front of it).  When ckpt
 // is set the state in front of every diagonal stage d is stored as image d of
 // the workgroup's area.
-template <bool SCALED>
+template <bool SCALED, bool MASKED = false>
 __device__ __forceinline__ void run_phases(double2 (&amp)[kRegAmps], const Prog& pp, Ctx& cx, int p0,
                                            bool diag_only_first, bool ckpt, bool use_ftab = false) {
     const VQA_CAS PhaseOp* ph = pp.phases;
@@ -825,7 +918,8 @@ __device__ __forceinline__ void run_phases(double2 (&amp)[kRegAmps], const Prog&
         if (flags & PH_DIAG) {
             const int did = d0.z;
             if (ckpt) store_state(amp, cx.area, (unsigned)did * cx.image_bytes, cx.nthr, cx.tid());
-            do_diag(amp, pp, cx, did, use_ftab);
+            if constexpr (MASKED) do_diag_masked(amp, pp, cx, did);
+            else do_diag(amp, pp, cx, did, use_ftab);
         }
         VQA_STAMP(13)
     }
@@ -1088,11 +1182,25 @@ __device__ __forceinline__ void thread_constants(const Prog& pp, unsigned short*
         unsigned c[kRegBits];
 #pragma unroll
         for (int j = 0; j < kRegBits; ++j) c[j] = (pp.signs[sg].cross[j][wi] >> bi) & 1u;
-        // bit 0: the thread's own parity; bit 1 + j: the flip that register bit j brings (the signs between
-        // register bits, rr_par, are the same for every thread and are read where they are applied)
-        unsigned m = base;
+        unsigned m = 0;
+        if (BLOCK == 1024) {
+            // the masked form (do_diag_masked): bit r = sign of entry r
+            const unsigned rr = pp.signs[sg].rr_par;
 #pragma unroll
-        for (int j = 0; j < kRegBits; ++j) m |= c[j] << (1 + j);
+            for (int r = 0; r < kRegAmps; ++r) {
+                unsigned sb = base ^ ((rr >> r) & 1u);
+#pragma unroll
+                for (int j = 0; j < kRegBits; ++j)
+                    if (r & (1 << j)) sb ^= c[j];
+                m |= sb << r;
+            }
+        } else {
+            // bit 0: the thread's own parity; bit 1 + j: the flip that register bit j brings (the signs between
+            // register bits, rr_par, are the same for every thread and are read where they are applied)
+            m = base;
+#pragma unroll
+            for (int j = 0; j < kRegBits; ++j) m |= c[j] << (1 + j);
+        }
         smask[sg * BLOCK + tid] = (unsigned short)m;
     }
 }
@@ -1169,7 +1277,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : BLOCK == 512 ? 2 : VQA_W
 #pragma unroll
         for (int r = 0; r < kRegAmps; ++r) amp[r] = make_double2(0.0, 0.0);
         if (t == 0) amp[0].x = 1.0;
-        run_phases<SCALED>(amp, pp, cx, 0, false, false);
+        run_phases<SCALED, BLOCK == 1024>(amp, pp, cx, 0, false, false);
         measure(amp, a, pp, cx, red, parity, e, live, valid, nullptr);
     }
 }
@@ -1445,7 +1553,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : BLOCK == 512 ? 2 : BLOCK
         __threadfence_block();
         // the thread-only factors of the diagonal stages, by halves of the thread bits (unpatched tables)
         __syncthreads();
-        for (int i = tid; i < ND * (FE + kRegBits); i += BLOCK) {
+        for (int i = tid; i < (BLOCK == 1024 ? 0 : ND * (FE + kRegBits)); i += BLOCK) {
             const int d = i / (FE + kRegBits), e = i - d * (FE + kRegBits);
             const double2* p1 = cx.ph1 + pp.ddesc[d].ph1_base;
             cplx f = { 1.0, 0.0 };
@@ -1533,7 +1641,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : BLOCK == 512 ? 2 : BLOCK
             // the next run's record travels while this run computes
             if (ri + 1 < NL && (tid & 63) < 8) nx = recs[(size_t)live[ri + 1] * 8 + (tid & 63)];
             // (a run that patches a phase slot works the thread-only factors out bit by bit)
-            if (!VQA_ABL(a, 8)) run_phases<true>(amp, pp, cx, pc0, rdiag >= 0, r < 0, id_b < 0 && id_a < 0);
+            if (!VQA_ABL(a, 8))
+                run_phases<true, BLOCK == 1024>(amp, pp, cx, pc0, rdiag >= 0, r < 0, !(VQA_EXP & 4) && id_b < 0 && id_a < 0);
             VQA_STAMP(2)
             if (r < 0) store_state(amp, cx.area, (unsigned)ND * cx.image_bytes, BLOCK, tid);
             if (!VQA_ABL(a, 4)) {

@@ -399,7 +399,8 @@ bool reg_compile(int n, int n_theta, const std::vector<vqa_op>& gate_list, RegPr
         std::vector<int> id(n);
         for (int p = 0; p < n; ++p) id[p] = p;
         candidates.push_back(id);
-        if (n > R) {
+        // (the 1024-thread workgroups apply the signs as a mask per thread, whatever the layout)
+        if (n > R && H.block < 1024) {
             for (int s = 2; s < n; ++s) {
                 int g = s, h = n;
                 while (h) { const int t = g % h; g = h; h = t; }
@@ -687,8 +688,9 @@ bool reg_compile(int n, int n_theta, const std::vector<vqa_op>& gate_list, RegPr
     // (explicit-list kernel: + the launch-wide cache of the input-free fused 2x2s, three entries each)
     P.lds_bytes = (size_t)H.S * tab1 + xbuf + fixed + (size_t)H.n_uent * 48;
     // + run record, unshifted values, the diagonal stages' thread-factor tables (two per stage, by halves of the thread bits)
+    // (the 1024-thread workgroups keep the diagonal stages' earlier form and have no such tables)
     P.lds_bytes_psr = tab1 + xbuf + fixed + 16 * 16 + 80 * sizeof(double) +
-                      (size_t)H.n_ddesc * ((1 << (T >> 1)) + (1 << (T - (T >> 1))) + kRegBits) * 16 + 16;
+                      (H.block >= 1024 ? 0 : (size_t)H.n_ddesc * ((1 << (T >> 1)) + (1 << (T - (T >> 1))) + kRegBits) * 16 + 16);
     // (64 bytes of margin for the kernels' few statically allocated words)
     if (std::max(P.lds_bytes, P.lds_bytes_psr) + 64 > 160 * 1024) { *why = "per-evaluation tables do not fit LDS"; return false; }
 
