@@ -528,6 +528,59 @@ def test_streaming_sweep_edge_cases(shared):
     assert e2.shape == (2, K, 3)
 
 
+def _axes_circuit(n, layers):
+    """Every qubit gets RX, RZ, RY, RX with parameters of their own in each layer (one fused 2x2 per qubit and
+    layer, four parameters in it), between them a CZ ring, a CZ ladder, Z gates and one ZZ sandwich with a
+    parameter in its RZ: parameters that resume behind their own layer on register, lane and wave bits, and
+    one that patches a phase slot."""
+    c = LearningCircuit(n)
+    rng = np.random.default_rng(n)
+    for q in range(n):
+        c.add_input_RY_gate(q, lambda x, q=q: x[q % len(x)])
+    for layer in range(layers):
+        for q in range(n):
+            c.add_parametric_RX_gate(q, rng.uniform(-3, 3))
+            c.add_parametric_RZ_gate(q, rng.uniform(-3, 3))
+            c.add_parametric_RY_gate(q, rng.uniform(-3, 3))
+            c.add_parametric_RX_gate(q, rng.uniform(-3, 3))
+        step = 1 if layer % 2 == 0 else 2
+        for q in range(n):
+            c.add_CZ_gate(q, (q + step) % n)
+        c.add_Z_gate((3 * layer + 1) % n)
+        c.add_CNOT_gate(layer % n, (layer + 5) % n)
+        c.add_parametric_RZ_gate((layer + 5) % n, rng.uniform(-3, 3))
+        c.add_CNOT_gate(layer % n, (layer + 5) % n)
+    for q in range(n):
+        c.add_parametric_RY_gate(q, rng.uniform(-3, 3))
+    return c
+
+
+@pytest.mark.parametrize("n", [10, 12, 13, 14])
+def test_sweep_resumes_behind_the_parameters_layer(n, monkeypatch):
+    """The sweep kernel of the register engine on a circuit whose parameters sit on every kind of position
+    (register, lane and wave bits) with rotations about all three axes: every row against the oracle; the
+    same circuit compiled without the search for the initial layout gives the same rows."""
+    rng = np.random.default_rng(40 + n)
+    x = rng.uniform(0, np.pi, (2, 5))
+    o1 = Observable(n); o1.add_operator(1.0, "Z 0"); o1.add_operator(-0.4, f"Z 3 Z {n - 1}")
+    o2 = Observable(n); o2.add_operator(0.7, f"Z {n // 2}")
+    rows = []
+    for search in (True, False):
+        if not search:
+            monkeypatch.setenv("VQA_REG_NO_LAYOUT_SEARCH", "1")
+        c = _axes_circuit(n, 3)
+        theta = np.random.default_rng(n).uniform(-3, 3, c.n_theta)
+        ia = c.input_angles(x)
+        got_e, got_m = c.psr_full(theta, ia, obs_list=[o1, o2], n_marg_bits=2)
+        rows.append((got_e, got_m))
+        if search:
+            si, sp, sv = cpu_oracle.psr_lists(2, c.n_theta)
+            want_e, want_m = cpu_oracle.eval_batch(c, theta, ia, si, sp, sv, obs_list=obs_tuples([o1, o2]), n_marg_bits=2)
+            assert np.abs(got_e.reshape(want_e.shape) - want_e).max() < TOL
+            assert np.abs(got_m.reshape(want_m.shape) - want_m).max() < TOL
+    assert np.abs(rows[0][0] - rows[1][0]).max() < TOL and np.abs(rows[0][1] - rows[1][1]).max() < TOL
+
+
 @pytest.mark.parametrize("n,shared", [(6, False), (7, True), (8, False), (9, True)])
 def test_grouped_small_sweeps(n, shared):
     """Below 10 qubits the register engine runs a sweep as groups of shifts of one sample that share
