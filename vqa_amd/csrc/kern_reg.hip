@@ -863,9 +863,13 @@ __device__ __forceinline__ void do_diag(double2 (&amp)[kRegAmps], const Prog& pp
 // diagonal stage (resuming from a checkpoint taken in front of it).  When ckpt
 // is set the state in front of every diagonal stage d is stored as image d of
 // the workgroup's area.
-template <bool SCALED, bool MASKED = false>
+struct NoHook {
+    __device__ __forceinline__ void operator()(double2 (&)[kRegAmps], int) const {}
+};
+// hook(amp, d): called in front of diagonal stage d (grouped sweeps: checkpoints in LDS, late corrections)
+template <bool SCALED, bool MASKED = false, class Hook = NoHook>
 __device__ __forceinline__ void run_phases(double2 (&amp)[kRegAmps], const Prog& pp, Ctx& cx, int p0,
-                                           bool diag_only_first, bool ckpt, bool use_ftab = false) {
+                                           bool diag_only_first, bool ckpt, bool use_ftab = false, Hook hook = Hook()) {
     const VQA_CAS PhaseOp* ph = pp.phases;
     int first_mask = diag_only_first ? (PH_DIAG | PH_END) : -1;
     VQA_STAMP0
@@ -918,6 +922,7 @@ __device__ __forceinline__ void run_phases(double2 (&amp)[kRegAmps], const Prog&
         if (flags & PH_DIAG) {
             const int did = d0.z;
             if (ckpt) store_state(amp, cx.area, (unsigned)did * cx.image_bytes, cx.nthr, cx.tid());
+            hook(amp, did);
             if constexpr (MASKED) do_diag_masked(amp, pp, cx, did);
             else do_diag(amp, pp, cx, did, use_ftab);
         }
@@ -1388,11 +1393,13 @@ __device__ __forceinline__ void apply_correction(double2 (&amp)[kRegAmps], const
 // then the runs one after the other, each: thread 0 undoes the previous patch
 // and applies this run's, everybody resumes from the checkpoint and measures.
 // The record of the next run is fetched while the current one computes.
-template <int BLOCK, bool SCALED = true, bool LATE = false>
+// LATE: 0 = patched tables; 1 = late resumption of the pair runs (sweep kernel); 2 = of every parameter that
+// allows it, the ones of the last U-stage included (grouped sweeps: the run named is the +shift one of the pair)
+template <int BLOCK, bool SCALED = true, int LATE = 0>
 __device__ __forceinline__ void make_run_record(const RegArgs& a, const Prog& pp, int r, const double* row, int NU, int N1,
                                                 RunRec* out) {
     const int i = pp.runs[r].param, variant = pp.runs[r].variant;
-    if (LATE && variant == 0 && pp.params[i].late_mask != 0) {
+    if (LATE && (variant == 0 || (LATE == 2 && variant == 1)) && pp.params[i].late_mask != 0) {
         // resumption behind the parameter's own U-stage (see ParamInfo): C = M' M^-1, taken into the frame of
         // the checkpoint in front of the diagonal stage, whose table still holds this 2x2's factor
         // diag(A, conj A): C' = diag(A, conj A)^-1 C diag(A, conj A)
@@ -1549,7 +1556,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : BLOCK == 512 ? 2 : BLOCK
         __syncthreads();
         prep_tables<true, true>(a, pp, tabs, j, 1, NU, N1, N2, tid, BLOCK);
         for (int r = tid; r < NR; r += BLOCK)
-            make_run_record<BLOCK, true, true>(a, pp, r, row, NU, N1, a.recs + (size_t)blockIdx.x * NR + r);
+            make_run_record<BLOCK, true, 1>(a, pp, r, row, NU, N1, a.recs + (size_t)blockIdx.x * NR + r);
         __threadfence_block();
         // the thread-only factors of the diagonal stages, by halves of the thread bits (unpatched tables)
         __syncthreads();
@@ -1877,6 +1884,141 @@ __global__ __launch_bounds__(64, VQA_GROUP_WAVES) void k_reg_group(RegArgs a) {
     }
 }
 
+
+// ---- grouped sweeps with late resumption -------------------------------------------------
+// The same division of work as k_reg_group (S states of a one-wave workgroup are S runs of one sample),
+// for run lists in which every parameter drives one rotation of one fused 2x2 (a.live: one entry per live
+// parameter, ordered by the U-stage of that 2x2).  Per (workgroup, sample) the unshifted circuit runs once
+// and leaves, in LDS, the state in front of every diagonal stage and the final state psi.  A chunk of S runs
+// starts from the checkpoint behind the U-stage of its first run, with ONE copy of the unshifted tables for
+// all states; in front of diagonal stage d the states whose parameter sits in U-stage d apply their
+// one-qubit correction (see ParamInfo) -- partners through an exchange buffer in LDS, so that one code path
+// serves whatever position the qubit has -- the states of the last U-stage behind the last phase; then every
+// state measures both shifted values against psi.  Until its correction a state simply repeats the
+// unshifted one.  Nothing is patched and nothing restarts from |0...0>.
+__global__ __launch_bounds__(64, VQA_GROUP_WAVES) void k_reg_group_late(RegArgs a) {
+    constexpr int BLOCK = 64;
+    constexpr bool SCALED = false;
+    extern __shared__ double2 smem[];
+    const Prog pp = load_prog(a.prog);
+    const int n = pp.H->n, T = pp.H->T, S = pp.H->S;
+    const int NU = pp.H->n_uent, N1 = pp.H->n_d1, N2 = pp.H->n_d2, ND = pp.H->n_ddesc;
+    const int tab_stride = NU + N1 + N2;
+    const int tid = threadIdx.x;
+    const int sl = tid >> T;
+    const int t = tid & ((1 << T) - 1);
+
+    double2* base = smem;                                  // the sample's unshifted tables (all states read them)
+    double2* bag = base + tab_stride;                      // (A, G) of every fused 2x2 (scratch of prep_base)
+    double2* xbuf = bag + 2 * (size_t)NU;
+    double* red = (double*)(xbuf + (pp.H->has_xpose ? ((size_t)1 << (n - 1)) : 0));
+    unsigned short* smask = (unsigned short*)(red + 128);
+    // the state in front of diagonal stage d as image d, the final state psi as image ND
+    double2* ckpt = (double2*)((char*)smask + (((size_t)pp.H->n_sign * BLOCK * 2 + 15) & ~(size_t)15));
+    double2* psi = ckpt + ((size_t)ND << n);
+    double* basev = (double*)(psi + ((size_t)1 << n));     // 79 values, squared norm of psi
+    RunRec* srec = (RunRec*)(basev + 80) + sl;
+    double2* xch = (double2*)((RunRec*)(basev + 80) + S);  // exchange buffer: [state][amplitude r][thread]
+
+    Ctx cx;
+    cx.mat = base;
+    cx.ph1 = base + NU;
+    cx.ph2 = cx.ph1 + N1;
+    cx.xbuf = (char*)xbuf;
+    cx.smask = smask;
+    cx.ftab = nullptr;
+    cx.T = T; cx.nthr = BLOCK;
+    cx.wave = 0; cx.tmask = (1 << T) - 1;
+    cx.xc_id = -1; cx.xc_wt = 0; cx.xc_rt = 0;
+    cx.area = __builtin_amdgcn_make_buffer_rsrc((void*)nullptr, 0, 0, 0x00020000);
+    cx.image_bytes = 0;
+#ifdef VQA_PROF
+    cx.flag_mask = -1;
+#endif
+    thread_constants<BLOCK>(pp, smask, T, t, tid);
+
+    const int K = 2 * a.spec.P + 1;
+    const int NL = a.n_live;
+    const int chunks = max((NL + S - 1) / S, 1);
+    const int64_t total = a.E * chunks;
+    const int64_t w0 = total * blockIdx.x / gridDim.x, w1 = total * (blockIdx.x + 1) / gridDim.x;
+    const int end_pc = pp.H->n_phases - 1;
+    int64_t cur = -1;
+    unsigned parity = 0;
+    for (int64_t w = w0; w < w1; ++w) {
+        const int64_t j = w / chunks;
+        const int ch = (int)(w - j * chunks);
+        int b = a.spec.sel ? a.spec.sel[j] : (int)j;
+        const bool valid = a.spec.B == 0 || (unsigned)b < (unsigned)a.spec.B;
+        if (!valid) b = 0;
+        const double* row = a.input + (size_t)b * a.n_input;
+        __syncthreads();   // the previous item is done with the tables and the records
+        if (j != cur) {
+            // the sample's tables, then the unshifted circuit: checkpoints, psi and the unshifted values
+            prep_base<SCALED>(a, pp, base, bag, row, NU, N1, N2, tid, BLOCK);
+            cur = j;
+            __syncthreads();
+            double2 amp[kRegAmps];
+#pragma unroll
+            for (int q = 0; q < kRegAmps; ++q) amp[q] = make_double2(0.0, 0.0);
+            if (t == 0) amp[0].x = 1.0;
+            auto keep = [&](double2 (&v)[kRegAmps], int d) {
+                if (sl == 0) {
+#pragma unroll
+                    for (int q = 0; q < kRegAmps; ++q) ckpt[((size_t)d << n) + (q << T) + t] = v[q];
+                }
+            };
+            run_phases<SCALED, false>(amp, pp, cx, 0, false, false, false, keep);
+            keep(amp, ND);
+            const double nrm = measure(amp, a, pp, cx, red, parity, j * K, sl == 0, valid, sl == 0 ? basev : nullptr);
+            if (tid == 0) basev[79] = nrm;
+            __syncthreads();
+        }
+        // the chunk: state sl takes entry ch * S + sl of the list
+        const int li = ch * S + sl;
+        const bool live = li < NL;
+        if (live && t == 0) make_run_record<BLOCK, SCALED, 2>(a, pp, a.live[li], row, NU, N1, srec);
+        __syncthreads();
+        int my_stage = 1 << 30, my_mask = 0, kout = 0;
+        if (live) {
+            my_stage = srec->out[2];
+            my_mask = srec->ids[3];
+            kout = srec->out[1];
+        }
+        const int u0 = __builtin_amdgcn_readfirstlane(my_stage);   // (the list is ordered by stage: state 0's is the first)
+        double2 amp[kRegAmps];
+#pragma unroll
+        for (int q = 0; q < kRegAmps; ++q) amp[q] = ckpt[((size_t)u0 << n) + (q << T) + t];
+        // the correction of the states whose parameter sits in U-stage d (d == ND: the last one)
+        auto correct = [&](double2 (&v)[kRegAmps], int d) {
+            const bool mine = my_stage == d;
+            if (__ballot(mine) == 0) return;
+            if (mine) {
+                const int p = __ffs(my_mask) - 1;
+                const double2* rec = (const double2*)srec;
+                const double2 c00 = rec[0], c01 = rec[1], c10 = rec[2], c11 = rec[7];
+                double2* mine_x = xch + ((size_t)sl << (kRegBits + T));
+#pragma unroll
+                for (int q = 0; q < kRegAmps; ++q) mine_x[(q << T) + t] = v[q];
+                const int flip_q = p < kRegBits ? 1 << p : 0, flip_t = p < kRegBits ? 0 : 1 << (p - kRegBits);
+#pragma unroll
+                for (int q = 0; q < kRegAmps; ++q) {
+                    const double2 pa = mine_x[((q ^ flip_q) << T) + (t ^ flip_t)];
+                    const bool up = (((q | (t << kRegBits)) >> p) & 1) != 0;
+                    const double csx = up ? c11.x : c00.x, csy = up ? c11.y : c00.y;
+                    const double cox = up ? c10.x : c01.x, coy = up ? c10.y : c01.y;
+                    clane_inplace(v[q].x, v[q].y, pa.x, pa.y, csx, csy, cox, coy);
+                }
+            }
+        };
+        const int pc0 = u0 < ND ? pp.ddesc[u0].pc : end_pc;
+        run_phases<SCALED, false>(amp, pp, cx, pc0, true, false, false, correct);
+        correct(amp, ND);
+        if (live)
+            measure_pair(amp, 0u, basev[79], (const double2*)srec, basev, a, pp, cx, red, parity, j * K + kout, valid, psi);
+    }
+}
+
 }  // namespace
 
 static int check_reg_call(const EvalCall& call) {
@@ -2059,6 +2201,16 @@ static size_t group_lds_bytes(const RegProgram& P, bool need_psi) {
     return P.lds_bytes + ((size_t)P.hdr.n_d1 + P.hdr.n_d2) * 16 +   // (lds_bytes counts 3 entries per fused 2x2 already)
            (need_psi ? ((size_t)16 << P.hdr.n) + 80 * sizeof(double) + (size_t)P.hdr.S * sizeof(RunRec) : 0);
 }
+// k_reg_group_late: one copy of the tables, (A, G) scratch, the checkpoints and psi, the unshifted values, one
+// run record per state, the exchange buffer (16 amplitudes of 64 threads)
+static size_t group_late_lds_bytes(const RegProgram& P) {
+    const RegHeader& H = P.hdr;
+    const size_t tab1 = ((size_t)H.n_uent + H.n_d1 + H.n_d2) * 16;
+    const size_t xbuf = H.has_xpose ? ((size_t)8 << H.n) : 0;
+    return tab1 + (size_t)H.n_uent * 32 + xbuf + 128 * sizeof(double) + (((size_t)H.n_sign * 64 * 2 + 15) & ~(size_t)15) +
+           ((size_t)(H.n_ddesc + 1) * 16 << H.n) + 80 * sizeof(double) + (size_t)H.S * sizeof(RunRec) +
+           (size_t)64 * kRegAmps * 16 + 64;
+}
 bool reg_engine_can_group(const RegProgram& P) {
     return P.hdr.S > 1 && P.hdr.block == 64 && group_lds_bytes(P, true) <= 160 * 1024;
 }
@@ -2106,7 +2258,38 @@ int reg_engine_group(const EvalCall& call, const void* d_prog, const RegProgram&
         for (int i = 0; i < call.c->n_theta; ++i)
             if (call.param_mask[i] && cone.dead[i]) m_dead.push_back(i);
     }
-    const std::vector<int32_t>& live_k = call.param_mask ? m_live : cone.group_live_k;
+    // late resumption (k_reg_group_late) when every run of the list belongs to a parameter that drives one
+    // rotation of one fused 2x2: one entry per parameter (the pair run, or the +shift run of a parameter of
+    // the last U-stage), ordered by the U-stage
+    auto late_list = [&](const uint8_t* mask, std::vector<int32_t>& out) {
+        out.clear();
+        if (getenv("VQA_NO_GROUP_LATE")) return;
+        for (int r = 0; r < P.hdr.n_runs; ++r) {
+            const int i = P.runs[r].param;
+            if (cone.dead[i] || (mask && !mask[i])) continue;
+            if (P.params[i].late_mask == 0) { out.clear(); return; }
+            if (P.runs[r].variant != 2) out.push_back(r);
+        }
+        std::stable_sort(out.begin(), out.end(), [&](int32_t x, int32_t y) {
+            return P.params[P.runs[x].param].late_diag < P.params[P.runs[y].param].late_diag;
+        });
+        // (the checkpoints and the exchange buffer must leave room for five workgroups on a CU: measured, seven and
+        // eight qubits -- 45 and 52 KB, three workgroups -- are 14 % and 47 % slower this way, six and fewer 30-140 % faster)
+        const size_t lds = group_late_lds_bytes(P);
+        if (lds > 32 * 1024) out.clear();
+    };
+    {
+        std::lock_guard<std::mutex> lk(call.c->mu);
+        if (!cone.group_late_built) {
+            late_list(nullptr, cone.group_late_k);
+            cone.group_late_built = true;
+        }
+    }
+    std::vector<int32_t> m_late;
+    if (call.param_mask) late_list(call.param_mask, m_late);
+    const std::vector<int32_t>& late_k = call.param_mask ? m_late : cone.group_late_k;
+    const bool late = !late_k.empty();
+    const std::vector<int32_t>& live_k = late ? late_k : call.param_mask ? m_live : cone.group_live_k;
     const std::vector<int32_t>& dead_list = call.param_mask ? m_dead : cone.dead_list;
     const size_t n_live = live_k.size(), n_dead = dead_list.size();
     void* ws = nullptr;
@@ -2121,13 +2304,15 @@ int reg_engine_group(const EvalCall& call, const void* d_prog, const RegProgram&
     a.live = d_live;
     a.n_live = (int)n_live;
     a.need_psi = live_k[0] >= 0;
-    const size_t lds = group_lds_bytes(P, a.need_psi != 0);
-    VQA_HIP(hipFuncSetAttribute((const void*)k_reg_group, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const size_t lds = late ? group_late_lds_bytes(P) : group_lds_bytes(P, a.need_psi != 0);
+    const void* fn = late ? (const void*)k_reg_group_late : (const void*)k_reg_group;
+    VQA_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t items = (int64_t)n_samples * (int64_t)std::max<size_t>((n_live + S - 1) / S, 1);
     const int by_lds = (int)((160 * 1024) / std::max<size_t>(lds, 1));
     const int per_cu = std::max(1, std::min(VQA_GROUP_WAVES * 4, by_lds));
     const int grid = (int)std::min<int64_t>(items, (int64_t)256 * per_cu);
-    hipLaunchKernelGGL(k_reg_group, dim3(grid), dim3(64), lds, call.stream, a);
+    if (late) hipLaunchKernelGGL(k_reg_group_late, dim3(grid), dim3(64), lds, call.stream, a);
+    else hipLaunchKernelGGL(k_reg_group, dim3(grid), dim3(64), lds, call.stream, a);
     VQA_HIP(hipGetLastError());
     if (n_dead) {
         const int K = 2 * call.c->n_theta + 1;

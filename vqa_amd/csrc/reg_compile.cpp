@@ -628,10 +628,12 @@ bool reg_compile(int n, int n_theta, const std::vector<vqa_op>& gate_list, RegPr
             pi.late_mask = 0;
             pi.pad = 0;
         }
-        // resumption behind the parameter's own U-stage (see ParamInfo)
-        for (int u = 0; u + 1 < NU; ++u) {
+        // resumption behind the parameter's own U-stage (see ParamInfo); behind the last U-stage there is no
+        // diagonal stage: late_diag = ND names the final state, late_pc the closing phase (grouped sweeps)
+        for (int u = 0; u < NU; ++u) {
+            const bool last = u + 1 == NU;
             for (auto& kv : uidx[u]) {
-                const int pos = dlayout[u].pos_of[kv.first];
+                const int pos = last ? lay.pos_of[kv.first] : dlayout[u].pos_of[kv.first];
                 // (a wave bit: the partner amplitudes come through the transposition buffer, when the program has one)
                 if (pos >= R + L && P.n_xpose == 0) continue;
                 for (int i = 0; i < n_theta; ++i) {
@@ -639,8 +641,8 @@ bool reg_compile(int n, int n_theta, const std::vector<vqa_op>& gate_list, RegPr
                     if (pi.ref_count != 1) continue;
                     const PatchRef& ref = P.refs[pi.ref_begin];
                     if (ref.kind != 0 || ref.index != kv.second || ref.coef_sum == 0.0) continue;
-                    pi.late_diag = u;
-                    pi.late_pc = P.ddesc[u].pc;
+                    pi.late_diag = last ? ND : u;
+                    pi.late_pc = last ? (int)P.phases.size() - 1 : P.ddesc[u].pc;
                     pi.late_mask = 1 << pos;
                 }
             }

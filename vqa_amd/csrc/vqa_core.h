@@ -136,6 +136,8 @@ struct ConeInfo {
     std::vector<int32_t> reg_live_runs;      // engine 2: runs of the live parameters, in run order
     bool group_built = false;
     std::vector<int32_t> group_live_k;       // engine 2, small circuits: runs of the live parameters, pair runs first
+    bool group_late_built = false;
+    std::vector<int32_t> group_late_k;       // engine 2, grouped sweeps with late resumption: one run per live parameter, by U-stage (empty: not available)
     bool hbm_built = false;
     std::vector<int32_t> hbm_ord, hbm_ord_pass, hbm_unused;   // engine 3: the sweep plan's lists without the dead
     std::vector<double> hbm_coef;
