@@ -1896,6 +1896,9 @@ __global__ __launch_bounds__(64, VQA_GROUP_WAVES) void k_reg_group(RegArgs a) {
 // serves whatever position the qubit has -- the states of the last U-stage behind the last phase; then every
 // state measures both shifted values against psi.  Until its correction a state simply repeats the
 // unshifted one.  Nothing is patched and nothing restarts from |0...0>.
+// GCK: the checkpoints (not psi) live in the workgroup's area of a.ckpt in global memory instead of LDS
+// (seven qubits and more: in LDS they would leave room for too few workgroups on a CU)
+template <bool GCK>
 __global__ __launch_bounds__(64, VQA_GROUP_WAVES) void k_reg_group_late(RegArgs a) {
     constexpr int BLOCK = 64;
     constexpr bool SCALED = false;
@@ -1913,9 +1916,10 @@ __global__ __launch_bounds__(64, VQA_GROUP_WAVES) void k_reg_group_late(RegArgs 
     double2* xbuf = bag + 2 * (size_t)NU;
     double* red = (double*)(xbuf + (pp.H->has_xpose ? ((size_t)1 << (n - 1)) : 0));
     unsigned short* smask = (unsigned short*)(red + 128);
-    // the state in front of diagonal stage d as image d, the final state psi as image ND
-    double2* ckpt = (double2*)((char*)smask + (((size_t)pp.H->n_sign * BLOCK * 2 + 15) & ~(size_t)15));
-    double2* psi = ckpt + ((size_t)ND << n);
+    // the state in front of diagonal stage d as image d (LDS or global), the final state psi (LDS)
+    double2* lds_img = (double2*)((char*)smask + (((size_t)pp.H->n_sign * BLOCK * 2 + 15) & ~(size_t)15));
+    double2* ckpt = GCK ? a.ckpt + (size_t)blockIdx.x * ((size_t)ND << n) : lds_img;
+    double2* psi = GCK ? lds_img : lds_img + ((size_t)ND << n);
     double* basev = (double*)(psi + ((size_t)1 << n));     // 79 values, squared norm of psi
     RunRec* srec = (RunRec*)(basev + 80) + sl;
     double2* xch = (double2*)((RunRec*)(basev + 80) + S);  // exchange buffer: [state][amplitude r][thread]
@@ -1964,12 +1968,14 @@ __global__ __launch_bounds__(64, VQA_GROUP_WAVES) void k_reg_group_late(RegArgs 
             if (t == 0) amp[0].x = 1.0;
             auto keep = [&](double2 (&v)[kRegAmps], int d) {
                 if (sl == 0) {
+                    double2* img = d == ND ? psi : ckpt + ((size_t)d << n);
 #pragma unroll
-                    for (int q = 0; q < kRegAmps; ++q) ckpt[((size_t)d << n) + (q << T) + t] = v[q];
+                    for (int q = 0; q < kRegAmps; ++q) img[(q << T) + t] = v[q];
                 }
             };
             run_phases<SCALED, false>(amp, pp, cx, 0, false, false, false, keep);
             keep(amp, ND);
+            if (GCK) __threadfence_block();
             const double nrm = measure(amp, a, pp, cx, red, parity, j * K, sl == 0, valid, sl == 0 ? basev : nullptr);
             if (tid == 0) basev[79] = nrm;
             __syncthreads();
@@ -1987,8 +1993,11 @@ __global__ __launch_bounds__(64, VQA_GROUP_WAVES) void k_reg_group_late(RegArgs 
         }
         const int u0 = __builtin_amdgcn_readfirstlane(my_stage);   // (the list is ordered by stage: state 0's is the first)
         double2 amp[kRegAmps];
+        {
+            const double2* img = u0 == ND ? psi : ckpt + ((size_t)u0 << n);
 #pragma unroll
-        for (int q = 0; q < kRegAmps; ++q) amp[q] = ckpt[((size_t)u0 << n) + (q << T) + t];
+            for (int q = 0; q < kRegAmps; ++q) amp[q] = img[(q << T) + t];
+        }
         // the correction of the states whose parameter sits in U-stage d (d == ND: the last one)
         auto correct = [&](double2 (&v)[kRegAmps], int d) {
             const bool mine = my_stage == d;
@@ -2203,14 +2212,16 @@ static size_t group_lds_bytes(const RegProgram& P, bool need_psi) {
 }
 // k_reg_group_late: one copy of the tables, (A, G) scratch, the checkpoints and psi, the unshifted values, one
 // run record per state, the exchange buffer (16 amplitudes of 64 threads)
-static size_t group_late_lds_bytes(const RegProgram& P) {
+static size_t group_late_lds_bytes(const RegProgram& P, bool global_ckpt) {
     const RegHeader& H = P.hdr;
     const size_t tab1 = ((size_t)H.n_uent + H.n_d1 + H.n_d2) * 16;
     const size_t xbuf = H.has_xpose ? ((size_t)8 << H.n) : 0;
     return tab1 + (size_t)H.n_uent * 32 + xbuf + 128 * sizeof(double) + (((size_t)H.n_sign * 64 * 2 + 15) & ~(size_t)15) +
-           ((size_t)(H.n_ddesc + 1) * 16 << H.n) + 80 * sizeof(double) + (size_t)H.S * sizeof(RunRec) +
+           ((size_t)((global_ckpt ? 0 : H.n_ddesc) + 1) * 16 << H.n) + 80 * sizeof(double) + (size_t)H.S * sizeof(RunRec) +
            (size_t)64 * kRegAmps * 16 + 64;
 }
+// (the checkpoints in LDS must leave room for five workgroups on a CU; else they go to global memory)
+static bool group_late_global_ckpt(const RegProgram& P) { return group_late_lds_bytes(P, false) > 32 * 1024; }
 bool reg_engine_can_group(const RegProgram& P) {
     return P.hdr.S > 1 && P.hdr.block == 64 && group_lds_bytes(P, true) <= 160 * 1024;
 }
@@ -2273,10 +2284,7 @@ int reg_engine_group(const EvalCall& call, const void* d_prog, const RegProgram&
         std::stable_sort(out.begin(), out.end(), [&](int32_t x, int32_t y) {
             return P.params[P.runs[x].param].late_diag < P.params[P.runs[y].param].late_diag;
         });
-        // (the checkpoints and the exchange buffer must leave room for five workgroups on a CU: measured, seven and
-        // eight qubits -- 45 and 52 KB, three workgroups -- are 14 % and 47 % slower this way, six and fewer 30-140 % faster)
-        const size_t lds = group_late_lds_bytes(P);
-        if (lds > 32 * 1024) out.clear();
+        if (group_late_lds_bytes(P, group_late_global_ckpt(P)) > 32 * 1024) out.clear();
     };
     {
         std::lock_guard<std::mutex> lk(call.c->mu);
@@ -2288,31 +2296,41 @@ int reg_engine_group(const EvalCall& call, const void* d_prog, const RegProgram&
     std::vector<int32_t> m_late;
     if (call.param_mask) late_list(call.param_mask, m_late);
     const std::vector<int32_t>& late_k = call.param_mask ? m_late : cone.group_late_k;
-    const bool late = !late_k.empty();
+    bool late = !late_k.empty();
+    // (a call that must not allocate has a fixed workspace: when the global checkpoints do not fit it, the earlier form runs)
+    if (late && group_late_global_ckpt(P) &&
+        call_workspace_room(call) < (size_t)256 * VQA_GROUP_WAVES * 4 * ((size_t)P.hdr.n_ddesc * 16 << P.hdr.n) + (1 << 20))
+        late = false;
     const std::vector<int32_t>& live_k = late ? late_k : call.param_mask ? m_live : cone.group_live_k;
     const std::vector<int32_t>& dead_list = call.param_mask ? m_dead : cone.dead_list;
     const size_t n_live = live_k.size(), n_dead = dead_list.size();
+    // launch shape (known here: the late form's global checkpoints are carved per workgroup)
+    const bool gck = late && group_late_global_ckpt(P);
+    const size_t lds = late ? group_late_lds_bytes(P, gck) : group_lds_bytes(P, live_k[0] >= 0);
+    const int64_t items = (int64_t)n_samples * (int64_t)std::max<size_t>((n_live + S - 1) / S, 1);
+    const int by_lds = (int)((160 * 1024) / std::max<size_t>(lds, 1));
+    const int per_cu = std::max(1, std::min(VQA_GROUP_WAVES * 4, by_lds));
+    const int grid = (int)std::min<int64_t>(items, (int64_t)256 * per_cu);
     void* ws = nullptr;
     const size_t live_part = (n_live * sizeof(int32_t) + 15) & ~(size_t)15;   // (16-byte aligned lists)
-    rc = call_workspace(call, live_part + n_dead * sizeof(int32_t) + 256, &ws);
+    const size_t dead_part = (n_dead * sizeof(int32_t) + 255) & ~(size_t)255;
+    const size_t ck_bytes = gck ? (size_t)grid * ((size_t)P.hdr.n_ddesc * 16 << P.hdr.n) : 0;
+    rc = call_workspace(call, live_part + dead_part + ck_bytes + 512, &ws);
     if (rc) return rc;
     int32_t* d_live = (int32_t*)ws;
     int32_t* d_dead = (int32_t*)((char*)ws + live_part);
+    a.ckpt = (double2*)((char*)ws + ((live_part + dead_part + 255) & ~(size_t)255));
     // (the cached lists live as long as the circuit; a per-call list is waited for below)
     if (n_live && (rc = call_upload(call, d_live, live_k.data(), n_live * sizeof(int32_t)))) return rc;
     if (n_dead && (rc = call_upload(call, d_dead, dead_list.data(), n_dead * sizeof(int32_t)))) return rc;
     a.live = d_live;
     a.n_live = (int)n_live;
     a.need_psi = live_k[0] >= 0;
-    const size_t lds = late ? group_late_lds_bytes(P) : group_lds_bytes(P, a.need_psi != 0);
-    const void* fn = late ? (const void*)k_reg_group_late : (const void*)k_reg_group;
+    const void* fn = !late ? (const void*)k_reg_group : gck ? (const void*)k_reg_group_late<true> : (const void*)k_reg_group_late<false>;
     VQA_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int64_t items = (int64_t)n_samples * (int64_t)std::max<size_t>((n_live + S - 1) / S, 1);
-    const int by_lds = (int)((160 * 1024) / std::max<size_t>(lds, 1));
-    const int per_cu = std::max(1, std::min(VQA_GROUP_WAVES * 4, by_lds));
-    const int grid = (int)std::min<int64_t>(items, (int64_t)256 * per_cu);
-    if (late) hipLaunchKernelGGL(k_reg_group_late, dim3(grid), dim3(64), lds, call.stream, a);
-    else hipLaunchKernelGGL(k_reg_group, dim3(grid), dim3(64), lds, call.stream, a);
+    if (!late) hipLaunchKernelGGL(k_reg_group, dim3(grid), dim3(64), lds, call.stream, a);
+    else if (gck) hipLaunchKernelGGL(k_reg_group_late<true>, dim3(grid), dim3(64), lds, call.stream, a);
+    else hipLaunchKernelGGL(k_reg_group_late<false>, dim3(grid), dim3(64), lds, call.stream, a);
     VQA_HIP(hipGetLastError());
     if (n_dead) {
         const int K = 2 * call.c->n_theta + 1;
