@@ -191,6 +191,57 @@ __device__ __forceinline__ double elem_angle_c(const VQA_CAS ElemGate* g, const 
 // inserted in front of that rotation (derivative direction of the parameter).
 // gp = the unit factor of the exact 2x2 that the engine leaves out: e^{i d}, times i
 // in the second scaled lane form, times G when there is no stage in front to take it.
+// the 2x2 of one gate of a fused entry
+__device__ __forceinline__ void elem_matrix(const VQA_CAS ElemGate* g, const double* theta, const double* row, int sparam,
+                                            double sval, cplx& g00, cplx& g01, cplx& g10, cplx& g11) {
+    const int kind = g->kind;
+    const double r2 = 0.70710678118654752440;
+    double c = 1.0, sn = 0.0;
+    if (kind >= VQA_GATE_RX) sincos(0.5 * elem_angle_c(g, theta, row, sparam, sval), &sn, &c);
+    switch (kind) {
+    case VQA_GATE_H: g00 = { r2, 0 }; g01 = { r2, 0 }; g10 = { r2, 0 }; g11 = { -r2, 0 }; break;
+    case VQA_GATE_X: g00 = { 0, 0 }; g01 = { 1, 0 }; g10 = { 1, 0 }; g11 = { 0, 0 }; break;
+    case VQA_GATE_Y: g00 = { 0, 0 }; g01 = { 0, -1 }; g10 = { 0, 1 }; g11 = { 0, 0 }; break;
+    case VQA_GATE_Z: g00 = { 1, 0 }; g01 = { 0, 0 }; g10 = { 0, 0 }; g11 = { -1, 0 }; break;
+    case VQA_GATE_RX: g00 = { c, 0 }; g01 = { 0, sn }; g10 = { 0, sn }; g11 = { c, 0 }; break;
+    case VQA_GATE_RY: g00 = { c, 0 }; g01 = { sn, 0 }; g10 = { -sn, 0 }; g11 = { c, 0 }; break;
+    default: /* RZ */ g00 = { c, sn }; g01 = { 0, 0 }; g10 = { 0, 0 }; g11 = { c, -sn }; break;
+    }
+}
+
+// C = M' M^-1 for the rotation that parameter i drives inside fused entry u, M' being M with the rotation's
+// generator P in front of it: with M = L R K (L the gates behind the rotation R), M' = L R P K and P
+// commuting with R, C = L P L^-1 -- only the gates behind the rotation enter
+__device__ __forceinline__ void late_generator(const Prog& pp, int u, const double* theta, const double* row, int i,
+                                               cplx& c00, cplx& c01, cplx& c10, cplx& c11) {
+    const int ubegin = pp.uent[u].begin, ucount = pp.uent[u].count;
+    bool found = false;
+    c00 = { 1, 0 }; c01 = { 0, 0 }; c10 = { 0, 0 }; c11 = { 1, 0 };
+    for (int j = 0; j < ucount; ++j) {
+        const VQA_CAS ElemGate* g = pp.elems + ubegin + j;
+        const int kind = g->kind;
+        if (!found) {
+            if (kind >= VQA_GATE_RX && g->src == VQA_SRC_THETA && g->idx == i) {
+                found = true;
+                if (kind == VQA_GATE_RX) { c00 = { 0, 0 }; c01 = { 1, 0 }; c10 = { 1, 0 }; c11 = { 0, 0 }; }
+                else if (kind == VQA_GATE_RY) { c00 = { 0, 0 }; c01 = { 0, -1 }; c10 = { 0, 1 }; c11 = { 0, 0 }; }
+                else c11 = { -1, 0 };
+            }
+            continue;
+        }
+        cplx g00, g01, g10, g11;
+        elem_matrix(g, theta, row, -1, 0.0, g00, g01, g10, g11);
+        auto add = [](cplx x, cplx y) { return cplx{ x.x + y.x, x.y + y.y }; };
+        // C <- g C g^-1 (g unitary)
+        const cplx t00 = add(cmul(g00, c00), cmul(g01, c10)), t01 = add(cmul(g00, c01), cmul(g01, c11));
+        const cplx t10 = add(cmul(g10, c00), cmul(g11, c10)), t11 = add(cmul(g10, c01), cmul(g11, c11));
+        c00 = add(cmul(t00, cconj(g00)), cmul(t01, cconj(g01)));
+        c01 = add(cmul(t00, cconj(g10)), cmul(t01, cconj(g11)));
+        c10 = add(cmul(t10, cconj(g00)), cmul(t11, cconj(g01)));
+        c11 = add(cmul(t10, cconj(g10)), cmul(t11, cconj(g11)));
+    }
+}
+
 // the 2x2 of U-entry u multiplied out (see compute_uentry for the arguments)
 __device__ __forceinline__ void uentry_product(const Prog& pp, int u, const double* theta, const double* row, int sparam,
                                                double sval, int pparam, cplx& m00, cplx& m01, cplx& m10, cplx& m11) {
@@ -200,18 +251,7 @@ __device__ __forceinline__ void uentry_product(const Prog& pp, int u, const doub
         const VQA_CAS ElemGate* g = pp.elems + ubegin + j;
         const int kind = g->kind;
         cplx g00, g01, g10, g11;
-        const double r2 = 0.70710678118654752440;
-        double c = 1.0, sn = 0.0;
-        if (kind >= VQA_GATE_RX) sincos(0.5 * elem_angle_c(g, theta, row, sparam, sval), &sn, &c);
-        switch (kind) {
-        case VQA_GATE_H: g00 = { r2, 0 }; g01 = { r2, 0 }; g10 = { r2, 0 }; g11 = { -r2, 0 }; break;
-        case VQA_GATE_X: g00 = { 0, 0 }; g01 = { 1, 0 }; g10 = { 1, 0 }; g11 = { 0, 0 }; break;
-        case VQA_GATE_Y: g00 = { 0, 0 }; g01 = { 0, -1 }; g10 = { 0, 1 }; g11 = { 0, 0 }; break;
-        case VQA_GATE_Z: g00 = { 1, 0 }; g01 = { 0, 0 }; g10 = { 0, 0 }; g11 = { -1, 0 }; break;
-        case VQA_GATE_RX: g00 = { c, 0 }; g01 = { 0, sn }; g10 = { 0, sn }; g11 = { c, 0 }; break;
-        case VQA_GATE_RY: g00 = { c, 0 }; g01 = { sn, 0 }; g10 = { -sn, 0 }; g11 = { c, 0 }; break;
-        default: /* RZ */ g00 = { c, sn }; g01 = { 0, 0 }; g10 = { 0, 0 }; g11 = { c, -sn }; break;
-        }
+        elem_matrix(g, theta, row, sparam, sval, g00, g01, g10, g11);
         if (kind >= VQA_GATE_RX && g->src == VQA_SRC_THETA && g->idx == pparam) {
             const cplx h00 = g00, h01 = g01, h10 = g10, h11 = g11;
             if (kind == VQA_GATE_RX) {          // g X
@@ -1393,11 +1433,12 @@ __device__ __forceinline__ void apply_correction(double2 (&amp)[kRegAmps], const
 // then the runs one after the other, each: thread 0 undoes the previous patch
 // and applies this run's, everybody resumes from the checkpoint and measures.
 // The record of the next run is fetched while the current one computes.
+// bag: the (A, G) of the sample's unshifted fused 2x2s where the caller keeps them (else A is worked out again).
 // LATE: 0 = patched tables; 1 = late resumption of the pair runs (sweep kernel); 2 = of every parameter that
 // allows it, the ones of the last U-stage included (grouped sweeps: the run named is the +shift one of the pair)
 template <int BLOCK, bool SCALED = true, int LATE = 0>
 __device__ __forceinline__ void make_run_record(const RegArgs& a, const Prog& pp, int r, const double* row, int NU, int N1,
-                                                RunRec* out) {
+                                                RunRec* out, const double2* bag = nullptr) {
     const int i = pp.runs[r].param, variant = pp.runs[r].variant;
     if (LATE && (variant == 0 || (LATE == 2 && variant == 1)) && pp.params[i].late_mask != 0) {
         // resumption behind the parameter's own U-stage (see ParamInfo): C = M' M^-1, taken into the frame of
@@ -1405,17 +1446,16 @@ __device__ __forceinline__ void make_run_record(const RegArgs& a, const Prog& pp
         // diag(A, conj A): C' = diag(A, conj A)^-1 C diag(A, conj A)
         const int index = pp.refs[pp.params[i].ref_begin].index;
         const double coef = pp.refs[pp.params[i].ref_begin].coef_sum;
-        cplx m00, m01, m10, m11, n00, n01, n10, n11;
-        uentry_product(pp, index, a.theta, row, -1, 0.0, -1, m00, m01, m10, m11);
-        uentry_product(pp, index, a.theta, row, -1, 0.0, i, n00, n01, n10, n11);
-        auto add = [](cplx x, cplx y) { return cplx{ x.x + y.x, x.y + y.y }; };
-        cplx c00 = add(cmul(n00, cconj(m00)), cmul(n01, cconj(m01)));
-        cplx c01 = add(cmul(n00, cconj(m10)), cmul(n01, cconj(m11)));
-        cplx c10 = add(cmul(n10, cconj(m00)), cmul(n11, cconj(m01)));
-        cplx c11 = add(cmul(n10, cconj(m10)), cmul(n11, cconj(m11)));
-        double2 mv;
-        cplx A, G, gp;
-        compute_uentry<SCALED>(pp, index, a.theta, row, -1, 0.0, -1, mv, A, G, gp);
+        cplx c00, c01, c10, c11;
+        late_generator(pp, index, a.theta, row, i, c00, c01, c10, c11);
+        cplx A;
+        if (bag) {
+            A = { bag[2 * index].x, bag[2 * index].y };
+        } else {
+            double2 mv;
+            cplx G, gp;
+            compute_uentry<SCALED>(pp, index, a.theta, row, -1, 0.0, -1, mv, A, G, gp);
+        }
         const cplx A2 = cmul(A, A);
         c01 = cmul(c01, cconj(A2));
         c10 = cmul(c10, A2);
@@ -1921,8 +1961,11 @@ __global__ __launch_bounds__(64, VQA_GROUP_WAVES) void k_reg_group_late(RegArgs 
     double2* ckpt = GCK ? a.ckpt + (size_t)blockIdx.x * ((size_t)ND << n) : lds_img;
     double2* psi = GCK ? lds_img : lds_img + ((size_t)ND << n);
     double* basev = (double*)(psi + ((size_t)1 << n));     // 79 values, squared norm of psi
-    RunRec* srec = (RunRec*)(basev + 80) + sl;
-    double2* xch = (double2*)((RunRec*)(basev + 80) + S);  // exchange buffer: [state][amplitude r][thread]
+    double2* xch = (double2*)(basev + 80);                 // exchange buffer: [state][amplitude r][thread]
+    // run records, 64 at a time (one per lane; the chunks of a batch read theirs from the workgroup's area)
+    RunRec* grec = a.recs + (size_t)blockIdx.x * 64;
+    int64_t rec_j = -1;
+    int rec_batch = -1;
 
     Ctx cx;
     cx.mat = base;
@@ -1983,8 +2026,16 @@ __global__ __launch_bounds__(64, VQA_GROUP_WAVES) void k_reg_group_late(RegArgs 
         // the chunk: state sl takes entry ch * S + sl of the list
         const int li = ch * S + sl;
         const bool live = li < NL;
-        if (live && t == 0) make_run_record<BLOCK, SCALED, 2>(a, pp, a.live[li], row, NU, N1, srec);
-        __syncthreads();
+        const int batch = (ch * S) >> 6;
+        if (j != rec_j || batch != rec_batch) {
+            const int lj = (batch << 6) + tid;
+            if (lj >= ch * S && lj < NL) make_run_record<BLOCK, SCALED, 2>(a, pp, a.live[lj], row, NU, N1, grec + tid, bag);
+            rec_j = j;
+            rec_batch = batch;
+            __threadfence_block();
+            __syncthreads();
+        }
+        const RunRec* srec = grec + (li & 63);
         int my_stage = 1 << 30, my_mask = 0, kout = 0;
         if (live) {
             my_stage = srec->out[2];
@@ -2217,8 +2268,7 @@ static size_t group_late_lds_bytes(const RegProgram& P, bool global_ckpt) {
     const size_t tab1 = ((size_t)H.n_uent + H.n_d1 + H.n_d2) * 16;
     const size_t xbuf = H.has_xpose ? ((size_t)8 << H.n) : 0;
     return tab1 + (size_t)H.n_uent * 32 + xbuf + 128 * sizeof(double) + (((size_t)H.n_sign * 64 * 2 + 15) & ~(size_t)15) +
-           ((size_t)((global_ckpt ? 0 : H.n_ddesc) + 1) * 16 << H.n) + 80 * sizeof(double) + (size_t)H.S * sizeof(RunRec) +
-           (size_t)64 * kRegAmps * 16 + 64;
+           ((size_t)((global_ckpt ? 0 : H.n_ddesc) + 1) * 16 << H.n) + 80 * sizeof(double) + (size_t)64 * kRegAmps * 16 + 64;
 }
 // (the checkpoints in LDS must leave room for five workgroups on a CU; else they go to global memory)
 static bool group_late_global_ckpt(const RegProgram& P) { return group_late_lds_bytes(P, false) > 32 * 1024; }
@@ -2297,29 +2347,42 @@ int reg_engine_group(const EvalCall& call, const void* d_prog, const RegProgram&
     if (call.param_mask) late_list(call.param_mask, m_late);
     const std::vector<int32_t>& late_k = call.param_mask ? m_late : cone.group_late_k;
     bool late = !late_k.empty();
-    // (a call that must not allocate has a fixed workspace: when the global checkpoints do not fit it, the earlier form runs)
-    if (late && group_late_global_ckpt(P) &&
-        call_workspace_room(call) < (size_t)256 * VQA_GROUP_WAVES * 4 * ((size_t)P.hdr.n_ddesc * 16 << P.hdr.n) + (1 << 20))
-        late = false;
-    const std::vector<int32_t>& live_k = late ? late_k : call.param_mask ? m_live : cone.group_live_k;
     const std::vector<int32_t>& dead_list = call.param_mask ? m_dead : cone.dead_list;
-    const size_t n_live = live_k.size(), n_dead = dead_list.size();
-    // launch shape (known here: the late form's global checkpoints are carved per workgroup)
-    const bool gck = late && group_late_global_ckpt(P);
-    const size_t lds = late ? group_late_lds_bytes(P, gck) : group_lds_bytes(P, live_k[0] >= 0);
-    const int64_t items = (int64_t)n_samples * (int64_t)std::max<size_t>((n_live + S - 1) / S, 1);
-    const int by_lds = (int)((160 * 1024) / std::max<size_t>(lds, 1));
-    const int per_cu = std::max(1, std::min(VQA_GROUP_WAVES * 4, by_lds));
-    const int grid = (int)std::min<int64_t>(items, (int64_t)256 * per_cu);
-    void* ws = nullptr;
-    const size_t live_part = (n_live * sizeof(int32_t) + 15) & ~(size_t)15;   // (16-byte aligned lists)
+    const size_t n_dead = dead_list.size();
     const size_t dead_part = (n_dead * sizeof(int32_t) + 255) & ~(size_t)255;
-    const size_t ck_bytes = gck ? (size_t)grid * ((size_t)P.hdr.n_ddesc * 16 << P.hdr.n) : 0;
-    rc = call_workspace(call, live_part + dead_part + ck_bytes + 512, &ws);
+    // launch shape and workspace (the late form's run records and global checkpoints are carved per workgroup)
+    const std::vector<int32_t>* live_p = nullptr;
+    bool gck = false;
+    size_t lds = 0, live_part = 0, ck_bytes = 0, rec_bytes = 0;
+    int grid = 0;
+    auto shape = [&]() {
+        live_p = late ? &late_k : call.param_mask ? &m_live : &cone.group_live_k;
+        const size_t nl = live_p->size();
+        gck = late && group_late_global_ckpt(P);
+        lds = late ? group_late_lds_bytes(P, gck) : group_lds_bytes(P, (*live_p)[0] >= 0);
+        const int64_t items = (int64_t)n_samples * (int64_t)std::max<size_t>((nl + S - 1) / S, 1);
+        const int by_lds = (int)((160 * 1024) / std::max<size_t>(lds, 1));
+        const int per_cu = std::max(1, std::min(VQA_GROUP_WAVES * 4, by_lds));
+        grid = (int)std::min<int64_t>(items, (int64_t)256 * per_cu);
+        live_part = (nl * sizeof(int32_t) + 15) & ~(size_t)15;   // (16-byte aligned lists)
+        ck_bytes = gck ? (size_t)grid * ((size_t)P.hdr.n_ddesc * 16 << P.hdr.n) : 0;
+        rec_bytes = late ? (size_t)grid * 64 * sizeof(RunRec) : 0;
+    };
+    shape();
+    // (a call that must not allocate has a fixed workspace: when the late form's areas do not fit it, the earlier form runs)
+    if (late && call_workspace_room(call) < live_part + dead_part + ck_bytes + rec_bytes + 1024) {
+        late = false;
+        shape();
+    }
+    const std::vector<int32_t>& live_k = *live_p;
+    const size_t n_live = live_k.size();
+    void* ws = nullptr;
+    rc = call_workspace(call, live_part + dead_part + ck_bytes + rec_bytes + 1024, &ws);
     if (rc) return rc;
     int32_t* d_live = (int32_t*)ws;
     int32_t* d_dead = (int32_t*)((char*)ws + live_part);
     a.ckpt = (double2*)((char*)ws + ((live_part + dead_part + 255) & ~(size_t)255));
+    a.recs = (RunRec*)((char*)a.ckpt + ((ck_bytes + 255) & ~(size_t)255));
     // (the cached lists live as long as the circuit; a per-call list is waited for below)
     if (n_live && (rc = call_upload(call, d_live, live_k.data(), n_live * sizeof(int32_t)))) return rc;
     if (n_dead && (rc = call_upload(call, d_dead, dead_list.data(), n_dead * sizeof(int32_t)))) return rc;
