@@ -1744,18 +1744,24 @@ __device__ __forceinline__ void prep_base(const RegArgs& a, const Prog& pp, doub
         }
         base[NU + k] = make_double2(ph.x, ph.y);
     }
-    // even U-stages first: no two entries of one round update the same phase slot
-    for (int parity = 0; parity < 2; ++parity) {
-        __syncthreads();
-        for (int u = tid; u < NU; u += nthr) {
-            if (pp.uent[u].parity != parity) continue;
-            const int d_before = pp.uent[u].d_before, d_after = pp.uent[u].d_after;
+    // every entry once; its factors join the phase slots around it in two rounds, even U-stages first:
+    // no two entries of one round update the same slot
+    for (int u0 = 0; u0 < NU; u0 += nthr) {
+        const int u = u0 + tid;
+        const bool have = u < NU;
+        cplx A = { 1, 0 }, G = { 1, 0 };
+        if (have) {
             double2 cs;
-            cplx A, G, gp;
+            cplx gp;
             compute_uentry<SCALED>(pp, u, a.theta, row, -1, 0.0, -1, cs, A, G, gp);
             base[u] = cs;
             bag[2 * u] = make_double2(A.x, A.y);
             bag[2 * u + 1] = make_double2(G.x, G.y);
+        }
+        for (int parity = 0; parity < 2; ++parity) {
+            __syncthreads();
+            if (!have || pp.uent[u].parity != parity) continue;
+            const int d_before = pp.uent[u].d_before, d_after = pp.uent[u].d_after;
             if (d_before >= 0) {
                 const double2 p = base[NU + d_before];
                 const cplx q = cmul({ p.x, p.y }, G);
