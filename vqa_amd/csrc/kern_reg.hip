@@ -1934,14 +1934,17 @@ __global__ __launch_bounds__(64, VQA_GROUP_WAVES) void k_reg_group(RegArgs a) {
 // ---- grouped sweeps with late resumption -------------------------------------------------
 // The same division of work as k_reg_group (S states of a one-wave workgroup are S runs of one sample),
 // for run lists in which every parameter drives one rotation of one fused 2x2 (a.live: one entry per live
-// parameter, ordered by the U-stage of that 2x2).  Per (workgroup, sample) the unshifted circuit runs once
-// and leaves, in LDS, the state in front of every diagonal stage and the final state psi.  A chunk of S runs
-// starts from the checkpoint behind the U-stage of its first run, with ONE copy of the unshifted tables for
-// all states; in front of diagonal stage d the states whose parameter sits in U-stage d apply their
-// one-qubit correction (see ParamInfo) -- partners through an exchange buffer in LDS, so that one code path
-// serves whatever position the qubit has -- the states of the last U-stage behind the last phase; then every
-// state measures both shifted values against psi.  Until its correction a state simply repeats the
-// unshifted one.  Nothing is patched and nothing restarts from |0...0>.
+// parameter, ordered by the U-stage of that 2x2; the kernel's own list has the unshifted circuit in front as
+// entry 0).  Per (workgroup, sample) the unshifted circuit runs once -- as state 0 of the sample's first chunk,
+// whose other states run from |0...0> beside it, or on its own when the workgroup's share of the sample starts
+// at a later chunk -- and leaves the state in front of every diagonal stage and the final state psi.  A later
+// chunk of S runs starts from the checkpoint behind the U-stage of its first run, with ONE copy of the
+// unshifted tables for all states; in front of diagonal stage d the states whose parameter sits in U-stage d
+// apply their one-qubit correction (see ParamInfo) -- partners through an exchange buffer in LDS, so that one
+// code path serves whatever position the qubit has -- the states of the last U-stage behind the last phase;
+// then every state measures both shifted values against psi.  Until its correction a state simply repeats
+// the unshifted one.  Nothing is patched.  The run records are built 64 at a time, one per lane, in the
+// workgroup's area of a.recs.
 // GCK: the checkpoints (not psi) live in the workgroup's area of a.ckpt in global memory instead of LDS
 // (seven qubits and more: in LDS they would leave room for too few workgroups on a CU)
 template <bool GCK>
@@ -1970,7 +1973,6 @@ __global__ __launch_bounds__(64, VQA_GROUP_WAVES) void k_reg_group_late(RegArgs 
     double2* xch = (double2*)(basev + 80);                 // exchange buffer: [state][amplitude r][thread]
     // run records, 64 at a time (one per lane; the chunks of a batch read theirs from the workgroup's area)
     RunRec* grec = a.recs + (size_t)blockIdx.x * 64;
-    int64_t rec_j = -1;
     int rec_batch = -1;
 
     Ctx cx;
@@ -1992,7 +1994,8 @@ __global__ __launch_bounds__(64, VQA_GROUP_WAVES) void k_reg_group_late(RegArgs 
 
     const int K = 2 * a.spec.P + 1;
     const int NL = a.n_live;
-    const int chunks = max((NL + S - 1) / S, 1);
+    // entry 0 of a sample is the unshifted circuit itself, entry e > 0 run e - 1 of the list
+    const int chunks = (NL + 1 + S - 1) / S;
     const int64_t total = a.E * chunks;
     const int64_t w0 = total * blockIdx.x / gridDim.x, w1 = total * (blockIdx.x + 1) / gridDim.x;
     const int end_pc = pp.H->n_phases - 1;
@@ -2006,82 +2009,88 @@ __global__ __launch_bounds__(64, VQA_GROUP_WAVES) void k_reg_group_late(RegArgs 
         if (!valid) b = 0;
         const double* row = a.input + (size_t)b * a.n_input;
         __syncthreads();   // the previous item is done with the tables and the records
-        if (j != cur) {
-            // the sample's tables, then the unshifted circuit: checkpoints, psi and the unshifted values
+        const bool fresh = j != cur;
+        if (fresh) {
             prep_base<SCALED>(a, pp, base, bag, row, NU, N1, N2, tid, BLOCK);
             cur = j;
             __syncthreads();
-            double2 amp[kRegAmps];
-#pragma unroll
-            for (int q = 0; q < kRegAmps; ++q) amp[q] = make_double2(0.0, 0.0);
-            if (t == 0) amp[0].x = 1.0;
-            auto keep = [&](double2 (&v)[kRegAmps], int d) {
-                if (sl == 0) {
-                    double2* img = d == ND ? psi : ckpt + ((size_t)d << n);
-#pragma unroll
-                    for (int q = 0; q < kRegAmps; ++q) img[(q << T) + t] = v[q];
-                }
-            };
-            run_phases<SCALED, false>(amp, pp, cx, 0, false, false, false, keep);
-            keep(amp, ND);
-            if (GCK) __threadfence_block();
-            const double nrm = measure(amp, a, pp, cx, red, parity, j * K, sl == 0, valid, sl == 0 ? basev : nullptr);
-            if (tid == 0) basev[79] = nrm;
-            __syncthreads();
         }
-        // the chunk: state sl takes entry ch * S + sl of the list
-        const int li = ch * S + sl;
-        const bool live = li < NL;
+        // the chunk: state sl takes entry ch * S + sl
+        const int e = ch * S + sl;
+        const bool live = e >= 1 && e <= NL;
         const int batch = (ch * S) >> 6;
-        if (j != rec_j || batch != rec_batch) {
-            const int lj = (batch << 6) + tid;
-            if (lj >= ch * S && lj < NL) make_run_record<BLOCK, SCALED, 2>(a, pp, a.live[lj], row, NU, N1, grec + tid, bag);
-            rec_j = j;
+        if (fresh || batch != rec_batch) {
+            const int ej = (batch << 6) + tid;
+            if (ej >= ch * S && ej >= 1 && ej <= NL)
+                make_run_record<BLOCK, SCALED, 2>(a, pp, a.live[ej - 1], row, NU, N1, grec + tid, bag);
             rec_batch = batch;
             __threadfence_block();
             __syncthreads();
         }
-        const RunRec* srec = grec + (li & 63);
-        int my_stage = 1 << 30, my_mask = 0, kout = 0;
+        const RunRec* srec = grec + (e & 63);
+        int run_stage = 1 << 30, my_mask = 0, kout = 0;
         if (live) {
-            my_stage = srec->out[2];
+            run_stage = srec->out[2];
             my_mask = srec->ids[3];
             kout = srec->out[1];
         }
-        const int u0 = __builtin_amdgcn_readfirstlane(my_stage);   // (the list is ordered by stage: state 0's is the first)
-        double2 amp[kRegAmps];
-        {
-            const double2* img = u0 == ND ? psi : ckpt + ((size_t)u0 << n);
+        // A workgroup's first item of a sample also runs the unshifted circuit from |0...0>, which leaves the
+        // checkpoints, psi and the unshifted values: as state 0 of chunk 0, side by side with the first S - 1
+        // runs (which then start from |0...0> too), or as a pass of its own in front of a later chunk.
+        for (int pass = fresh && ch != 0 ? 0 : 1; pass < 2; ++pass) {
+            const bool zero = fresh && (pass == 0 || ch == 0);
+            const int my_stage = pass == 1 ? run_stage : 1 << 30;
+            const int u0 = __builtin_amdgcn_readfirstlane(my_stage);   // (the list is ordered by stage: state 0's is the first)
+            double2 amp[kRegAmps];
+            if (zero) {
 #pragma unroll
-            for (int q = 0; q < kRegAmps; ++q) amp[q] = img[(q << T) + t];
-        }
-        // the correction of the states whose parameter sits in U-stage d (d == ND: the last one)
-        auto correct = [&](double2 (&v)[kRegAmps], int d) {
-            const bool mine = my_stage == d;
-            if (__ballot(mine) == 0) return;
-            if (mine) {
-                const int p = __ffs(my_mask) - 1;
-                const double2* rec = (const double2*)srec;
-                const double2 c00 = rec[0], c01 = rec[1], c10 = rec[2], c11 = rec[7];
-                double2* mine_x = xch + ((size_t)sl << (kRegBits + T));
+                for (int q = 0; q < kRegAmps; ++q) amp[q] = make_double2(0.0, 0.0);
+                if (t == 0) amp[0].x = 1.0;
+            } else {
+                const double2* img = u0 == ND ? psi : ckpt + ((size_t)u0 << n);
 #pragma unroll
-                for (int q = 0; q < kRegAmps; ++q) mine_x[(q << T) + t] = v[q];
-                const int flip_q = p < kRegBits ? 1 << p : 0, flip_t = p < kRegBits ? 0 : 1 << (p - kRegBits);
-#pragma unroll
-                for (int q = 0; q < kRegAmps; ++q) {
-                    const double2 pa = mine_x[((q ^ flip_q) << T) + (t ^ flip_t)];
-                    const bool up = (((q | (t << kRegBits)) >> p) & 1) != 0;
-                    const double csx = up ? c11.x : c00.x, csy = up ? c11.y : c00.y;
-                    const double cox = up ? c10.x : c01.x, coy = up ? c10.y : c01.y;
-                    clane_inplace(v[q].x, v[q].y, pa.x, pa.y, csx, csy, cox, coy);
-                }
+                for (int q = 0; q < kRegAmps; ++q) amp[q] = img[(q << T) + t];
             }
-        };
-        const int pc0 = u0 < ND ? pp.ddesc[u0].pc : end_pc;
-        run_phases<SCALED, false>(amp, pp, cx, pc0, true, false, false, correct);
-        correct(amp, ND);
-        if (live)
-            measure_pair(amp, 0u, basev[79], (const double2*)srec, basev, a, pp, cx, red, parity, j * K + kout, valid, psi);
+            // in front of diagonal stage d (d == ND: behind the last phase): the unshifted state leaves its image,
+            // the states whose parameter sits in U-stage d apply their correction
+            auto hook = [&](double2 (&v)[kRegAmps], int d) {
+                if (zero && sl == 0) {
+                    double2* img = d == ND ? psi : ckpt + ((size_t)d << n);
+#pragma unroll
+                    for (int q = 0; q < kRegAmps; ++q) img[(q << T) + t] = v[q];
+                }
+                const bool mine = my_stage == d;
+                if (__ballot(mine) == 0) return;
+                if (mine) {
+                    const int p = __ffs(my_mask) - 1;
+                    const double2* rec = (const double2*)srec;
+                    const double2 c00 = rec[0], c01 = rec[1], c10 = rec[2], c11 = rec[7];
+                    double2* mine_x = xch + ((size_t)sl << (kRegBits + T));
+#pragma unroll
+                    for (int q = 0; q < kRegAmps; ++q) mine_x[(q << T) + t] = v[q];
+                    const int flip_q = p < kRegBits ? 1 << p : 0, flip_t = p < kRegBits ? 0 : 1 << (p - kRegBits);
+#pragma unroll
+                    for (int q = 0; q < kRegAmps; ++q) {
+                        const double2 pa = mine_x[((q ^ flip_q) << T) + (t ^ flip_t)];
+                        const bool up = (((q | (t << kRegBits)) >> p) & 1) != 0;
+                        const double csx = up ? c11.x : c00.x, csy = up ? c11.y : c00.y;
+                        const double cox = up ? c10.x : c01.x, coy = up ? c10.y : c01.y;
+                        clane_inplace(v[q].x, v[q].y, pa.x, pa.y, csx, csy, cox, coy);
+                    }
+                }
+            };
+            const int pc0 = zero ? 0 : u0 < ND ? pp.ddesc[u0].pc : end_pc;
+            run_phases<SCALED, false>(amp, pp, cx, pc0, !zero, false, false, hook);
+            hook(amp, ND);
+            if (zero) {
+                if (GCK) __threadfence_block();
+                const double nrm = measure(amp, a, pp, cx, red, parity, j * K, sl == 0, valid, sl == 0 ? basev : nullptr);
+                if (tid == 0) basev[79] = nrm;
+                __syncthreads();
+            }
+            if (pass == 1 && live)
+                measure_pair(amp, 0u, basev[79], (const double2*)srec, basev, a, pp, cx, red, parity, j * K + kout, valid, psi);
+        }
     }
 }
 
@@ -2366,7 +2375,8 @@ int reg_engine_group(const EvalCall& call, const void* d_prog, const RegProgram&
         const size_t nl = live_p->size();
         gck = late && group_late_global_ckpt(P);
         lds = late ? group_late_lds_bytes(P, gck) : group_lds_bytes(P, (*live_p)[0] >= 0);
-        const int64_t items = (int64_t)n_samples * (int64_t)std::max<size_t>((nl + S - 1) / S, 1);
+        // (the late form's list starts with the unshifted circuit itself)
+        const int64_t items = (int64_t)n_samples * (int64_t)std::max<size_t>((nl + (late ? 1 : 0) + S - 1) / S, 1);
         const int by_lds = (int)((160 * 1024) / std::max<size_t>(lds, 1));
         const int per_cu = std::max(1, std::min(VQA_GROUP_WAVES * 4, by_lds));
         grid = (int)std::min<int64_t>(items, (int64_t)256 * per_cu);
