@@ -227,7 +227,8 @@ struct XRec {                                 // one late gate: the amplitude ge
 struct SweepRec {
     uint32_t pos_lo, pos_hi;                  // 4 bits per entry: tpos[0 .. kThreadBits), then gpos[0 .. 4)
     int32_t flags;                            // bit s: rotation on group slot s; bit 4 + s: diag(1, b1) first; bit 8 + s: the
-                                              // two-shear form; bit 12 + s: the three-shear form; bit 16: operations from the records
+                                              // two-shear form; bit 12 + s: the three-shear form; bit 16: operations from the records;
+                                              // bit 20 + g: g of the (ascending) group positions lie in the low half of the tile positions
     int32_t run, next_run, x_begin, x_tab, x_count, nx_begin, nx_tab, op_begin, op_count;
     int32_t rot[4];                           // the rotations' records (b1 is read there when it is needed)
     double tu[4][2];                          // their shears
@@ -268,6 +269,12 @@ __device__ __forceinline__ bool gate_bit(int p, int64_t base, int i) {
 // 16 indices that differ in one position of each residue class mod 4 land in 16 different
 // 16-byte bank groups (the sweeps choose their thread bits accordingly)
 __device__ __forceinline__ int tile_slot(int i) { return i ^ ((i >> 4) & 15) ^ ((i >> 8) & 15); }
+
+// LDS slot of entry e of a 64-entry phase table: bits 4 and 5 are XORed onto bits 0 and 1.  The 16 lanes
+// of a row differ in one tile position of each residue class mod 4, so within a half of the positions
+// bit 4 never varies together with bit 0, nor bit 5 with bit 1: their entries land in different 16-byte
+// bank groups.  XOR-linear: slot(a | b) = slot(a) ^ slot(b) for disjoint a, b.
+__device__ __forceinline__ int tab_slot(int e) { return e ^ (e >> 4); }
 
 // the product of the 1-qubit gates [begin, begin + count) for every instance, in normal form:
 // mats[(ci * M + m) * 4 ..] = (tan(phi / 2), sin(phi)) or (-s / c, s c), A0, A1, b1
@@ -390,6 +397,9 @@ __global__ __launch_bounds__(kT) void k_prep_sweeps(const SweepDesc* __restrict_
     r.pos_lo = (uint32_t)pos;
     r.pos_hi = (uint32_t)(pos >> 32);
     r.flags = sd.op_count > 0 ? 1 << 16 : 0;
+    int glo = 0;
+    for (int j = 0; j < kGroup; ++j) glo += sd.gpos[j] < 6;
+    r.flags |= 1 << (20 + glo);
     r.run = sd.run; r.next_run = sd.next_run;
     r.x_begin = sd.x_begin; r.x_tab = sd.x_tab; r.x_count = sd.x_count;
     r.nx_begin = sd.nx_begin; r.nx_tab = sd.nx_tab;
@@ -568,6 +578,46 @@ __device__ __forceinline__ void apply_op(double2 (&v)[kTA], const OpRec& r, int6
 }
 
 
+// The table part of a diagonal run: amplitude r of the thread gets the product of the low table's entry
+// for the low six positions of its index and the high table's entry for the high six.  The group
+// positions ascend, GLO of them lie in the low half: the low entry then depends on the low GLO bits of
+// r only and the high entry on the others, 2^GLO + 2^(kGroup - GLO) table reads instead of two per
+// amplitude.  The side with fewer entries stays in registers, the other one is read entry by entry.
+template <int GLO>
+__device__ __forceinline__ void diag_tables(double2 (&v)[kTA], const double2* dt, int ib, const int (&off)[kTA]) {
+    constexpr int NL = 1 << GLO, NH = kTA >> GLO;
+    const int tlo = tab_slot(ib & 63), thi = 64 + tab_slot(ib >> 6);
+    if (NL <= NH) {
+        c2 lo[NL];
+#pragma unroll
+        for (int k = 0; k < NL; ++k) lo[k] = c2of(dt[tlo ^ tab_slot(off[k] & 63)]);
+#pragma unroll
+        for (int m = 0; m < NH; ++m) {
+            const c2 hi = c2of(dt[thi ^ tab_slot(off[m << GLO] >> 6)]);
+#pragma unroll
+            for (int k = 0; k < NL; ++k) {
+                const c2 ph = cm(lo[k], hi);
+                cmul_inplace(v[(m << GLO) | k].x, v[(m << GLO) | k].y, ph.x, ph.y);
+            }
+            if ((((m + 1) * NL) & 3) == 0) __builtin_amdgcn_sched_barrier(0);   // a few table reads in flight, not all
+        }
+    } else {
+        c2 hi[NH];
+#pragma unroll
+        for (int m = 0; m < NH; ++m) hi[m] = c2of(dt[thi ^ tab_slot(off[m << GLO] >> 6)]);
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const c2 lo = c2of(dt[tlo ^ tab_slot(off[k] & 63)]);
+#pragma unroll
+            for (int m = 0; m < NH; ++m) {
+                const c2 ph = cm(lo, hi[m]);
+                cmul_inplace(v[(m << GLO) | k].x, v[(m << GLO) | k].y, ph.x, ph.y);
+            }
+            if ((((k + 1) * NH) & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 // Sum of v over the 64 lanes of a wave (every lane gets it): DPP inside the rows of 16 lanes, then
 // the four row sums through scalar registers.
 template <int CTRL>
@@ -592,9 +642,19 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // Where the states of a launch are read and written, and what the pass measures at its end.
+// A state that branches off the running unshifted state inside a pass: where it starts.
+struct BranchRec {
+    int64_t src_off;          // its source, in amplitudes from PassIO::alt_src: the running state as it was in front of sweep `start`
+    int32_t start, pad;       // the first sweep of the pass that the state's own parameter can change: it runs the pass from there
+};
 struct PassIO {
     const double2* alt_src;   // states ci >= alt_from are read from here: the running unshifted state they branch off
     int alt_from;
+    const BranchRec* branch;  // not null: state ci >= alt_from reads alt_src + branch[ci].src_off and starts at sweep branch[ci].start
+    // state 0 (the running state) leaves the tile as it is in front of sweep s, for every bit s of snap_mask, in
+    // snap + (number of lower bits set) states: what the states that branch off in this pass start from
+    uint64_t snap_mask;
+    double2* snap;
     const double2* rd0;       // state 0 is read from here (nullptr: from its own place)
     double2* wr0;             // state 0 is written here (nullptr: to its own place)
     // MEAS: per Z-string (or marginal bin) the tile's sums of sign |phi|^2 and sign Re(conj(psi) phi), psi = F,
@@ -622,6 +682,13 @@ __global__ __launch_bounds__(kTT, kTileWaves) void k_tile_pass(double2* __restri
     const uint32_t tile_no = io.state_first ? blockIdx.x / (uint32_t)io.n_states : blockIdx.x & (n_tiles - 1);
     double2* own = st + ((int64_t)ci << a.n);
     const double2* s = ci >= io.alt_from ? io.alt_src : (ci == 0 && io.rd0) ? io.rd0 : own;
+    int s0 = 0;   // the first sweep this state runs
+    if (io.branch && ci >= io.alt_from) {
+        const BranchRec br = io.branch[ci];
+        s += br.src_off;
+        s0 = br.start;
+    }
+    const uint64_t snap_mask = ci == 0 ? io.snap_mask : 0;
     double2* sout = (ci == 0 && io.wr0) ? io.wr0 : own;
     const OpRec* __restrict__ my_ops = oprec + (int64_t)ci * a.n_ops_total;
     const double2* __restrict__ my_tab = pretab + (int64_t)ci * a.n_runs_total * 128;
@@ -665,17 +732,26 @@ __global__ __launch_bounds__(kTT, kTileWaves) void k_tile_pass(double2* __restri
                 const bool sel = (x.mode & 2) ? (b0 && b1) : (x.mode & 1) ? (b0 != b1) : b0;
                 ph = cm(ph, c2of(sel ? x.v1 : x.v0));
             }
-            dst[tid] = d2of(ph);
+            dst[(tid & 64) | tab_slot(tid & 63)] = d2of(ph);
         };
         double2 ahead = make_double2(1.0, 0.0);
-        if (a.first_run >= 0 && tid < 128) ahead = my_tab[a.first_run * 128 + tid];
+        SweepRec sw_next = my_sw[s0];
+        // the first diagonal run at or behind the first sweep
+        const int run0 = sw_next.run >= 0 ? sw_next.run : sw_next.next_run;
+        const int xb0 = sw_next.run >= 0 ? sw_next.x_begin : sw_next.nx_begin, xt0 = sw_next.run >= 0 ? sw_next.x_tab : sw_next.nx_tab;
+        if (run0 >= 0 && tid < 128) ahead = my_tab[run0 * 128 + tid];
 #pragma unroll
         for (int k = 0; k < kTA; ++k) tile[tile_slot(k * kTT + tid)] = pv[k];
-        if (a.first_run >= 0 && tid < 128) finish_table(ahead, a.first_xb, a.first_xt, dtab[0]);
+        if (run0 >= 0 && tid < 128) finish_table(ahead, xb0, xt0, dtab[0]);
         int cur = 0;   // which table the next diagonal run reads
-        SweepRec sw_next = my_sw[0];
-        for (int si = 0; si < ((abl & 1) ? 0 : a.n_sweeps); ++si) {
+        for (int si = s0; si < ((abl & 1) ? 0 : a.n_sweeps); ++si) {
             lds_barrier();   // the previous sweep's amplitudes (or the gathered tile) and the next table are in LDS
+            if ((snap_mask >> si) & 1) {
+                double2* snap = io.snap + ((int64_t)__popcll(snap_mask & (((uint64_t)1 << si) - 1)) << a.n);
+#pragma unroll
+                for (int k = 0; k < kTA; ++k) snap[base | g_tid | g_k[k]] = tile[tile_slot(k * kTT + tid)];
+                lds_barrier();   // everybody has read the tile before the sweep changes it
+            }
             const SweepRec sw = sw_next;
             sw_next = my_sw[min(si + 1, a.n_sweeps - 1)];   // on its way while this sweep runs
             const uint64_t pos = ((uint64_t)sw.pos_hi << 32) | sw.pos_lo;
@@ -724,13 +800,14 @@ __global__ __launch_bounds__(kTT, kTileWaves) void k_tile_pass(double2* __restri
 #undef VQA_ROT_SLOT
             }
             if (sw.run >= 0 && !(abl & 8)) {
-#pragma unroll
-                for (int r = 0; r < kTA; ++r) {
-                    const int i = ib | off[r];
-                    const c2 ph = cm(c2of(dt[i & 63]), c2of(dt[64 + (i >> 6)]));
-                    cmul_inplace(v[r].x, v[r].y, ph.x, ph.y);
-                    if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four amplitudes' table reads in flight, not all
-                }
+                // (one block per number of group positions in the low half, each updating the amplitudes in place)
+                // and behind a flag test of its own: tests the compiler can prove exclusive would cost a second copy of the state)
+                const int gf = sw.flags >> 20;
+                if (gf & 1) diag_tables<0>(v, dt, ib, off);
+                if (gf & 2) diag_tables<1>(v, dt, ib, off);
+                if (gf & 4) diag_tables<2>(v, dt, ib, off);
+                if (gf & 8) diag_tables<3>(v, dt, ib, off);
+                if (kGroup > 3 && (gf & 16)) diag_tables<kGroup>(v, dt, ib, off);
                 for (int k = sw.x_begin + sw.x_tab; k < sw.x_begin + sw.x_count; ++k) {
                     const XRec x = my_x[k];
                     // (two blocks, not an if / else: each updates the amplitudes in place)
@@ -860,6 +937,8 @@ struct TilePlan {
         std::vector<TileGate> xgates;  // the late gates
         std::vector<GroupOp> ops;
         std::vector<MatDesc> mats;     // gate ranges relative to this pass's gates
+        std::vector<int> mat_first;    // per fused 2x2: the first sweep of the pass whose outcome depends on it (the one whose
+                                       // diagonal run holds the factor in front of its rotation, or the rotation's own)
         std::vector<RunDesc> runs;     // likewise
         std::vector<SweepDesc> sweeps; // operations, runs and late gates in the pass's numbering
     };
@@ -875,10 +954,11 @@ struct TilePlan {
     std::vector<int> first_run;        // each pass's first diagonal run (plan numbering), -1: none
     std::vector<int> first_xb, first_xt;   // and its late gates (x_begin, x_tab)
     std::vector<int> pass_of_gate;     // gate index -> the pass that runs it
+    std::vector<int> first_sweep_of_gate;   // gate index -> the first sweep of that pass it can change (0 unless it sits in a fused 2x2)
     // parameter-shift sweeps (filled by plan_sweep): the parameters that drive exactly one
     // rotation, ordered by the pass of that rotation, and the ones that drive none
     bool sweepable = false;
-    std::vector<int32_t> ord, ord_pass, unused;
+    std::vector<int32_t> ord, ord_pass, ord_sweep, unused;
     std::vector<double> ord_coef;
 };
 
@@ -950,7 +1030,8 @@ static bool group_sweeps(TilePlan::Pass& pass, const std::vector<TileGate>& in_o
             bool touched = lo(p) >= 0 || ld(p) >= 0;
             for (const TileGate& d : pending) touched |= d.p0 == p || d.p1 == p;
             if (touched) pending.push_back(TileGate{ kGateD1B, p, -1, mat });
-            const int s = place(p, -1);
+            const int s = place(p, -1);   // (flushes the factor in front of the rotation, if any, to sweep last_flush)
+            pass.mat_first.push_back(touched ? std::min(last_flush, s) : s);
             sweeps[s].ops.push_back(HOp{ OP_ROT, p, -1, mat, touched ? 0 : 1, {} });
             pending.push_back(TileGate{ kGateD1A, p, -1, mat });
         } else if (tg.kind == VQA_GATE_CNOT) {
@@ -970,6 +1051,7 @@ static bool group_sweeps(TilePlan::Pass& pass, const std::vector<TileGate>& in_o
         // position of each residue class mod 4 (classes 0, 1, 2 first), the rest ascending
         for (int p = kTileBits - 1; p >= 0 && (int)hs.gpos.size() < kGroup; --p)
             if (fits(hs, p) && std::find(hs.gpos.begin(), hs.gpos.end(), p) == hs.gpos.end()) hs.gpos.push_back(p);
+        std::sort(hs.gpos.begin(), hs.gpos.end());   // ascending: the kernel's diagonal run counts on it
         std::vector<int> rest;
         for (int p = 0; p < kTileBits; ++p)
             if (std::find(hs.gpos.begin(), hs.gpos.end(), p) == hs.gpos.end()) rest.push_back(p);
@@ -1149,12 +1231,16 @@ static TilePlan plan_tiles(int n, const std::vector<vqa_op>& ops, const std::vec
     }
     std::reverse(plan.passes.begin(), plan.passes.end());
     plan.pass_of_gate.assign(ops.size(), -1);
+    plan.first_sweep_of_gate.assign(ops.size(), 0);
     for (size_t k = 0; k < plan.passes.size(); ++k) {
         const auto& p = plan.passes[k];
         plan.soff.push_back(plan.all_sweeps.size());
         const int gbase = (int)plan.all_gates.size(), mbase = (int)plan.all_mats.size(), obase = (int)plan.all_ops.size(),
                   rbase = (int)plan.all_runs.size(), xbase = (int)plan.all_xgates.size();
         for (const MatDesc& md : p.mats) plan.all_mats.push_back(MatDesc{ md.begin + gbase, md.count });
+        for (size_t mi = 0; mi < p.mats.size(); ++mi)
+            for (int gi = p.mats[mi].begin; gi < p.mats[mi].begin + p.mats[mi].count; ++gi)
+                plan.first_sweep_of_gate[p.gates[gi].g] = p.mat_first[mi];
         for (const RunDesc& rd : p.runs)
             plan.all_runs.push_back(RunDesc{ rd.g1_begin + gbase, rd.g1_count, rd.g2_begin + gbase, rd.g2_count });
         for (TileGate tg : p.gates) {
@@ -1217,11 +1303,13 @@ static void plan_sweep(TilePlan& plan, int n_theta, const std::vector<vqa_op>& o
         else plan.sweepable = false;
     }
     std::stable_sort(with.begin(), with.end(), [&](int a, int b) {
-        return plan.pass_of_gate[gate[a]] < plan.pass_of_gate[gate[b]];
+        const int pa = plan.pass_of_gate[gate[a]], pb = plan.pass_of_gate[gate[b]];
+        return pa != pb ? pa < pb : plan.first_sweep_of_gate[gate[a]] < plan.first_sweep_of_gate[gate[b]];
     });
     for (int i : with) {
         plan.ord.push_back(i);
         plan.ord_pass.push_back(plan.pass_of_gate[gate[i]]);
+        plan.ord_sweep.push_back(plan.first_sweep_of_gate[gate[i]]);
         plan.ord_coef.push_back(ops[gate[i]].coef);
     }
 }
@@ -2194,6 +2282,7 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
                 } else {
                     cone.hbm_ord.push_back(plan.ord[k]);
                     cone.hbm_ord_pass.push_back(plan.ord_pass[k]);
+                    cone.hbm_ord_sweep.push_back(plan.ord_sweep[k]);
                     cone.hbm_coef.push_back(plan.ord_coef[k]);
                 }
             }
@@ -2202,13 +2291,14 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
     }
     // a caller's parameter subset: per-call copies of the lists (the call then waits for the stream
     // before it returns, so that the asynchronous copies have read them)
-    std::vector<int32_t> m_ord, m_ord_pass, m_unused;
+    std::vector<int32_t> m_ord, m_ord_pass, m_ord_sweep, m_unused;
     std::vector<double> m_coef;
     if (call.param_mask) {
         for (size_t k = 0; k < cone.hbm_ord.size(); ++k) {
             if (!call.param_mask[cone.hbm_ord[k]]) continue;
             m_ord.push_back(cone.hbm_ord[k]);
             m_ord_pass.push_back(cone.hbm_ord_pass[k]);
+            m_ord_sweep.push_back(cone.hbm_ord_sweep[k]);
             m_coef.push_back(cone.hbm_coef[k]);
         }
         for (int32_t i : cone.hbm_unused)
@@ -2216,6 +2306,7 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
     }
     const std::vector<int32_t>& ord = call.param_mask ? m_ord : cone.hbm_ord;
     const std::vector<int32_t>& ord_pass = call.param_mask ? m_ord_pass : cone.hbm_ord_pass;
+    const std::vector<int32_t>& ord_sweep = call.param_mask ? m_ord_sweep : cone.hbm_ord_sweep;
     const std::vector<int32_t>& unused = call.param_mask ? m_unused : cone.hbm_unused;
     const std::vector<double>& ord_coef = call.param_mask ? m_coef : cone.hbm_coef;
     const int64_t D = (int64_t)1 << n;
@@ -2236,9 +2327,32 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
     fuse_plan(call, hl, D >> kTileBits, &fu, &fio);
     const int n_alt = fu.h_indep ? (int)hl.pd.plan->passes.size() : 1;   // places behind the Hadamard layer
     if (Cmax < 4 + n_alt) VQA_FAIL(VQA_ENOMEM, "not enough free device memory for %d %d-qubit states", 4 + n_alt, n);
-    const int C = (int)std::min<int64_t>(Cmax - 3 - n_alt, std::max(m, 1));
+    // Late branching.  A parameter's state equals the running unshifted state up to the first sweep of its
+    // pass that the parameter can change (ord_sweep).  The running state then runs the pass first and leaves
+    // the tile as it is in front of every such sweep (one place per distinct sweep of the pass), and the
+    // branching states start there instead of at the head of the pass.  Taken when it saves a tenth of
+    // the sweeps and the places cost at most a quarter of the parameter slots.
+    const size_t n_pass = plan.passes.size();
+    std::vector<uint64_t> snap_mask(n_pass, 0);
+    int n_snap = 0;
+    {
+        int64_t total = 0, saved = 0;
+        std::vector<int64_t> tail(n_pass + 1, 0);   // sweeps from pass k to the end
+        for (size_t k = n_pass; k-- > 0;) tail[k] = tail[k + 1] + (int64_t)plan.passes[k].sweeps.size();
+        for (int q = 0; q < m; ++q) {
+            total += tail[ord_pass[q]];
+            saved += ord_sweep[q];
+            snap_mask[ord_pass[q]] |= (uint64_t)1 << ord_sweep[q];
+        }
+        for (size_t k = 0; k < n_pass; ++k) n_snap = std::max(n_snap, __builtin_popcountll(snap_mask[k]));
+        const bool fits = Cmax - 3 - n_alt - n_snap >= std::min<int64_t>(m, 4 * (int64_t)n_snap);
+        if (m == 0 || saved * 10 < total || !fits || getenv("VQA_NO_LATE_BRANCH")) n_snap = 0;
+    }
+    const bool late = n_snap > 0;
+    const int C = (int)std::min<int64_t>(Cmax - 3 - n_alt - n_snap, std::max(m, 1));
     Carver cv;
-    const size_t o_st = cv.add((size_t)(C + 3 + n_alt) * D * sizeof(double2));
+    const size_t o_st = cv.add((size_t)(C + 3 + n_alt + n_snap) * D * sizeof(double2));
+    const size_t o_branch = cv.add((size_t)std::max(m, 1) * sizeof(BranchRec));
     const size_t o_tab = cv.add((size_t)(C + 2) * n_ops * sizeof(double2));
     const size_t nb_part = std::max<size_t>(nb, (fu.main || fu.h) ? (size_t)fu.n_tiles : 0);
     const size_t o_part = cv.add((size_t)C * nb_part * kZBatch * 2 * sizeof(double));
@@ -2259,6 +2373,8 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
     int32_t* d_ord = (int32_t*)(w + o_ord);
     double* d_coef = (double*)(w + o_coef);
     int32_t* d_unused = (int32_t*)(w + o_unused);
+    BranchRec* d_branch = (BranchRec*)(w + o_branch);
+    std::vector<BranchRec> h_branch;   // (the copy below has read it when hipMemcpyAsync returns: pageable memory)
     pd.buf = w + o_gate;
     pd.carve(w + o_inst, C + 2);
     rc = upload_plan(call, pd);
@@ -2275,12 +2391,19 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
     }
     if (n_unused > 0)
         VQA_HIP(hipMemcpyAsync(d_unused, unused.data(), (size_t)n_unused * sizeof(int32_t), hipMemcpyHostToDevice, call.stream));
-    const size_t n_pass = plan.passes.size();
+    if (late) {
+        for (int q = 0; q < m; ++q) {
+            const uint64_t below = snap_mask[ord_pass[q]] & (((uint64_t)1 << ord_sweep[q]) - 1);
+            h_branch.push_back(BranchRec{ (int64_t)__builtin_popcountll(below) * D, ord_sweep[q], 0 });
+        }
+        VQA_HIP(hipMemcpyAsync(d_branch, h_branch.data(), (size_t)m * sizeof(BranchRec), hipMemcpyHostToDevice, call.stream));
+    }
     double2* F = st;
     double2* R = st + D;
     double2* S = st + 2 * D;
     double2* R2 = st + (int64_t)(C + 2) * D;
     hl.alt = st + (int64_t)(C + 3) * D;   // the unshifted final state behind the Hadamard layer (n_alt places)
+    double2* snap = st + (int64_t)(C + 3 + n_alt) * D;   // late branching: the running state in front of the branching sweeps of a pass
     const unsigned gD = (unsigned)((D + kT - 1) / kT);
     HbmCommon h;
     h.n = n;
@@ -2337,7 +2460,49 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
             launch_mats(call, pd, tab, h.n_ops, 0, cnt + 2);
             for (; rpass < k0; ++rpass) launch_pass(call, pd, rpass, Rcur, 1, 1);
             int live = 0;
-            for (size_t k = k0; k < n_pass; ++k) {
+            for (size_t k = k0; late && k < n_pass; ++k) {
+                // Late branching: the running state (in place, table row 1) runs pass k once, beside the chunk's
+                // states that are under way when it has to move on with the chunk, and leaves the pass's
+                // branching points; the states that branch here start from those in a launch behind it.
+                // A later chunk that branches in the same pass finds the branching points still there.
+                int fresh = 0;
+                while (live + fresh < cnt && (size_t)ord_pass[a + live + fresh] == k) ++fresh;
+                PassIO io;
+                memset(&io, 0, sizeof(io));
+                io.alt_from = 1 << 30;
+                const bool run_r = rpass == k && (fresh > 0 || k < k1);
+                if (run_r) {
+                    io.snap_mask = snap_mask[k];
+                    io.snap = snap;
+                    rpass = k + 1;
+                }
+                PassIO bio;
+                memset(&bio, 0, sizeof(bio));
+                bio.alt_src = snap;
+                if (k < k1) {
+                    if (run_r) launch_pass(call, pd, k, R, 1, live + 1, &io);
+                    else launch_pass(call, pd, k, S, 2, live, &io);
+                    bio.alt_from = 0;
+                    bio.branch = d_branch + a + live;
+                    launch_pass(call, pd, k, S + (int64_t)live * D, 2 + live, fresh, &bio);
+                    live += fresh;
+                } else {
+                    if (run_r) launch_pass(call, pd, k, R, 1, 1, &io);
+                    bio.alt_from = live;
+                    bio.branch = d_branch + a;
+                    live += fresh;
+                    if (k + 1 == n_pass && fu.main) {
+                        memcpy(bio.z, fio.z, sizeof(bio.z));
+                        memcpy(bio.bin, fio.bin, sizeof(bio.bin));
+                        bio.nz = fio.nz;
+                        bio.F = F;
+                        bio.partial = partial;
+                        bio.write_state = fu.main_write ? 1 : 0;
+                    }
+                    launch_pass(call, pd, k, S, 2, live, &bio);
+                }
+            }
+            for (size_t k = k0; !late && k < n_pass; ++k) {
                 // the states whose rotation sits in this pass branch off the running state: they read it
                 int fresh = 0;
                 while (live + fresh < cnt && (size_t)ord_pass[a + live + fresh] == k) ++fresh;
@@ -2378,8 +2543,16 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
                 n_samples, m, n_pass, (long long)t_state_passes, (double)t_state_passes / std::max(n_samples, 1));
         for (size_t k = 0; k < n_pass; ++k) {
             const auto& p = plan.passes[k];
-            fprintf(stderr, "[vqa]   pass %2zu: %3zu gates, %2zu sweeps (%zu with a diagonal run), %2zu fused 2x2, %3zu register ops, %zu late gates\n",
-                    k, p.gates.size(), p.sweeps.size(), p.runs.size(), p.mats.size(), p.ops.size(), p.xgates.size());
+            int nb_ = 0, skip = 0;
+            std::vector<int> distinct;
+            for (size_t q = 0; q < plan.ord.size(); ++q)
+                if ((size_t)plan.ord_pass[q] == k && !cone.dead[plan.ord[q]]) {
+                    ++nb_;
+                    skip += plan.ord_sweep[q];
+                    if (std::find(distinct.begin(), distinct.end(), plan.ord_sweep[q]) == distinct.end()) distinct.push_back(plan.ord_sweep[q]);
+                }
+            fprintf(stderr, "[vqa]   pass %2zu: %3zu gates, %2zu sweeps (%zu with a diagonal run), %2zu fused 2x2, %3zu register ops, %zu late gates; %d live parameters branch here, %d sweeps in front of them in all, %zu distinct first sweeps\n",
+                    k, p.gates.size(), p.sweeps.size(), p.runs.size(), p.mats.size(), p.ops.size(), p.xgates.size(), nb_, skip, distinct.size());
         }
         t_state_passes = 0;
     }

@@ -139,7 +139,7 @@ struct ConeInfo {
     bool group_late_built = false;
     std::vector<int32_t> group_late_k;       // engine 2, grouped sweeps with late resumption: one run per live parameter, by U-stage (empty: not available)
     bool hbm_built = false;
-    std::vector<int32_t> hbm_ord, hbm_ord_pass, hbm_unused;   // engine 3: the sweep plan's lists without the dead
+    std::vector<int32_t> hbm_ord, hbm_ord_pass, hbm_ord_sweep, hbm_unused;   // engine 3: the sweep plan's lists without the dead
     std::vector<double> hbm_coef;
 };
 }  // namespace vqa
