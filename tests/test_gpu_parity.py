@@ -457,6 +457,31 @@ def test_parameter_subset_sweep(n, d, builder):
     assert np.abs(eh[:, [0, 2 * mine[0] + 1, 2 * mine[1] + 2]] - full_e.cpu().numpy()[:, [0, 2 * mine[0] + 1, 2 * mine[1] + 2]]).max() < TOL
 
 
+@pytest.mark.parametrize("cap", [None, 30, 12])
+def test_streaming_sweep_in_chunks_with_late_branching(cap, monkeypatch):
+    """IBM-HEA on 16 qubits, depth 3, on the HBM engine: the parameters' states branch off the running
+    state at the first sweep of their pass they can change.  With the number of states in HBM capped
+    the sweep runs in several chunks of parameters, and chunks that branch in the same pass share its
+    branching points (cap 30); a cap that leaves no room for branching points runs the earlier form
+    (cap 12).  Every row against the oracle, and one sample's rows again from a sweep of two samples."""
+    n, d = 16, 3
+    if cap is not None:
+        monkeypatch.setenv("VQA_HBM_MAX_STATES", str(cap))
+    c = create_ibm_HEA_ansatz(n, d, seed=2)
+    rng = np.random.default_rng(16)
+    theta = rng.uniform(0, 2 * np.pi, c.n_theta)
+    x = rng.uniform(0, np.pi, (2, n))
+    ia = c.input_angles(x)
+    z = Observable(n); z.add_operator(1.0, "Z 0"); z.add_operator(-0.4, "Z 3 Z 9"); z.add_operator(0.2, f"Z {n - 1}")
+    si, sp, sv = cpu_oracle.psr_lists(1, c.n_theta)
+    want_e, want_m = cpu_oracle.eval_batch(c, theta, ia[1:], si, sp, sv, obs_list=obs_tuples([z]), n_marg_bits=2)
+    got_e, got_m = c.psr_full(theta, ia, obs_list=[z], n_marg_bits=2)
+    assert np.abs(got_e[1].reshape(want_e.shape) - want_e).max() < TOL
+    assert np.abs(got_m[1].reshape(want_m.shape) - want_m).max() < TOL
+    one_e, one_m = c.psr_full(theta, ia[:1], obs_list=[z], n_marg_bits=2)
+    assert np.abs(one_e[0] - got_e[0]).max() < TOL and np.abs(one_m[0] - got_m[0]).max() < TOL
+
+
 def _edge_circuit(n, shared):
     """Parameters with a coefficient, a parameter that drives no gate, (optionally) one shared by two
     gates, CNOT sandwiches, input gates, rotations of every axis on low, middle and top qubits."""

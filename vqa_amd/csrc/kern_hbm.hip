@@ -245,7 +245,8 @@ struct TilePassArgs {
     int n_ops_total, n_runs_total, n_x_total, n_sweeps_total; // row lengths of the per-instance tables
     int sweep_off;                            // where the pass's sweeps start in a row
 #ifdef VQA_TILE_ABLATE
-    int ablate;                               // timing experiments (libvqahip_abl.so): bit 0 no sweeps, 1 no LDS traffic in the sweeps, 2 no register operations, 3 no diagonal runs
+    int ablate;                               // timing experiments (libvqahip_abl.so): bit 0 no sweeps, 1 no LDS traffic in the sweeps, 2 no register operations, 3 no diagonal runs,
+                                              // 4 no late gates in the tables, 5 no late gates that join the halves
 #endif
 };
 
@@ -678,8 +679,11 @@ __global__ __launch_bounds__(kTT, kTileWaves) void k_tile_pass(double2* __restri
     // workgroup number -> (tile, state); states first when they read a common state (its tile then
     // comes from HBM once for all of them)
     const uint32_t n_tiles = 1u << (a.n - kTileBits);
-    const int ci = io.state_first ? (int)(blockIdx.x % (uint32_t)io.n_states) : (int)(blockIdx.x >> (a.n - kTileBits));
-    const uint32_t tile_no = io.state_first ? blockIdx.x / (uint32_t)io.n_states : blockIdx.x & (n_tiles - 1);
+    // (states first: workgroups go round-robin to the eight XCDs, each with an L2 of its own, so the states of
+    // a tile take every eighth workgroup number: the tile of the common state then comes through one L2)
+    const uint32_t chunk = blockIdx.x >> 3;
+    const int ci = io.state_first ? (int)(chunk % (uint32_t)io.n_states) : (int)(blockIdx.x >> (a.n - kTileBits));
+    const uint32_t tile_no = io.state_first ? ((chunk / (uint32_t)io.n_states) << 3) | (blockIdx.x & 7) : blockIdx.x & (n_tiles - 1);
     double2* own = st + ((int64_t)ci << a.n);
     const double2* s = ci >= io.alt_from ? io.alt_src : (ci == 0 && io.rd0) ? io.rd0 : own;
     int s0 = 0;   // the first sweep this state runs
@@ -724,7 +728,7 @@ __global__ __launch_bounds__(kTT, kTileWaves) void k_tile_pass(double2* __restri
         auto finish_table = [&](double2 entry, int xb, int xt, double2* dst) {
             const int half = tid >> 6, i = half ? (tid & 63) << 6 : (tid & 63);
             c2 ph = c2of(entry);
-            for (int k = xb; k < xb + xt; ++k) {
+            for (int k = xb; k < xb + ((abl & 16) ? 0 : xt); ++k) {
                 const XRec x = my_x[k];
                 const int tp = x.p0 < 32 ? x.p0 : x.p1;   // the tile position it acts on, if any
                 if ((int)(tp < 32 && tp >= 6) != half) continue;
@@ -808,7 +812,7 @@ __global__ __launch_bounds__(kTT, kTileWaves) void k_tile_pass(double2* __restri
                 if (gf & 4) diag_tables<2>(v, dt, ib, off);
                 if (gf & 8) diag_tables<3>(v, dt, ib, off);
                 if (kGroup > 3 && (gf & 16)) diag_tables<kGroup>(v, dt, ib, off);
-                for (int k = sw.x_begin + sw.x_tab; k < sw.x_begin + sw.x_count; ++k) {
+                for (int k = sw.x_begin + sw.x_tab; k < sw.x_begin + ((abl & 32) ? sw.x_tab : sw.x_count); ++k) {
                     const XRec x = my_x[k];
                     // (two blocks, not an if / else: each updates the amplitudes in place)
                     if (x.mode & 2) {
@@ -2176,6 +2180,8 @@ static int chunk_plan(const EvalCall& call, double frac, size_t cap_bytes, int64
     Cmax = (int64_t)(budget / ((size_t)D * sizeof(double2)));
     if (Cmax < 1) VQA_FAIL(VQA_ENOMEM, "not enough free device memory for one %d-qubit state", n);
     Cmax = std::min<int64_t>(Cmax, 4096);
+    // (tests: a small cap makes a sweep run in several chunks of parameters on registers whose states would all fit)
+    if (const char* cap = getenv("VQA_HBM_MAX_STATES")) Cmax = std::min<int64_t>(Cmax, std::max(atoi(cap), 1));
     nb = (int)std::min<int64_t>(1024, std::max<int64_t>(1, D / (kT * 4)));
     return VQA_OK;
 }
@@ -2539,8 +2545,9 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
     }
     VQA_HIP(hipGetLastError());
     if (getenv("VQA_PLAN_DEBUG")) {
-        fprintf(stderr, "[vqa] sweep of %d samples: %d live parameters, %zu passes, %lld state passes in all (%.1f per sample)\n",
-                n_samples, m, n_pass, (long long)t_state_passes, (double)t_state_passes / std::max(n_samples, 1));
+        fprintf(stderr, "[vqa] sweep of %d samples: %d live parameters, %zu passes, %lld state passes in all (%.1f per sample); "
+                "%d parameter slots per chunk, %d places for branching points\n",
+                n_samples, m, n_pass, (long long)t_state_passes, (double)t_state_passes / std::max(n_samples, 1), C, n_snap);
         for (size_t k = 0; k < n_pass; ++k) {
             const auto& p = plan.passes[k];
             int nb_ = 0, skip = 0;
