@@ -480,6 +480,11 @@ def test_streaming_sweep_in_chunks_with_late_branching(cap, monkeypatch):
     assert np.abs(got_m[1].reshape(want_m.shape) - want_m).max() < TOL
     one_e, one_m = c.psr_full(theta, ia[:1], obs_list=[z], n_marg_bits=2)
     assert np.abs(one_e[0] - got_e[0]).max() < TOL and np.abs(one_m[0] - got_m[0]).max() < TOL
+    # a subset of the parameters (other chunks, other branching points in use)
+    mine = np.arange(2, c.n_theta, 5)
+    sub_e, sub_m = c.psr_full(theta, ia, obs_list=[z], n_marg_bits=2, params=mine)
+    rows = np.concatenate([[0], 2 * mine + 1, 2 * mine + 2])
+    assert np.abs(sub_e[:, rows] - got_e[:, rows]).max() < TOL and np.abs(sub_m[:, rows] - got_m[:, rows]).max() < TOL
 
 
 def _edge_circuit(n, shared):
