@@ -405,7 +405,32 @@ def other_configs(device):
         del c, x
         torch.cuda.empty_cache()
     out["28-qubit VQE: RY + CZ ring depth 6, Ising ring (56 Pauli terms), full gradient"] = vqe_config(device)
+    out["Iris classifier: 4 qubits, depth 3 (RY/RZ + CZ ring), 105 training samples, two-bit marginal"] = iris_config(device)
     return out
+
+
+def iris_config(device, B=105, reps=50):
+    """The classifier's circuit at the size of the Iris training set: one full parameter-shift sweep with the
+    marginal of qubits 0 and 1 (what the class probabilities are read from) per call; a call this small
+    is bound by the launch, not by the arithmetic."""
+    import torch
+
+    from vqa_amd import LearningCircuit
+    from vqa_amd.qml_utils import create_ry_rz_cz_ansatz
+
+    rng = np.random.default_rng(0)
+    c = create_ry_rz_cz_ansatz(4, 3, seed=0, circuit_cls=lambda nq: LearningCircuit(nq, device=device))
+    x = c.upload_inputs(rng.uniform(0.0, np.pi, (B, 4)))
+    th = torch.from_numpy(rng.uniform(0.0, 2 * np.pi, c.n_theta)).to(x.device)
+    c.psr_full(th, x, n_sel=B, n_marg_bits=2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        c.psr_full(th, x, n_sel=B, n_marg_bits=2)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    K = 2 * c.n_theta + 1
+    return {"gradients_per_sec": B / dt, "circuit_evals_per_sec": B * K / dt, "n_params": c.n_theta, "ms_per_call": 1e3 * dt}
 
 
 def vqe_config(device, n=28, d=6):
