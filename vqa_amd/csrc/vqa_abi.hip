@@ -40,6 +40,9 @@ struct DeviceState {
     bool ws_recorded = false;
     bool ws_touched = false;          // the call in progress has taken the workspace
     hipStream_t touch_stream = nullptr;
+    hipStream_t side[3] = { nullptr, nullptr, nullptr };   // call_side_streams (created on first use)
+    hipEvent_t side_done[3] = { nullptr, nullptr, nullptr };
+    hipEvent_t side_fork = nullptr;
 };
 static std::mutex g_dev_mu;
 static std::map<int, std::unique_ptr<DeviceState>> g_dev;
@@ -123,6 +126,33 @@ int call_workspace(const EvalCall& call, size_t bytes, void** out) {
     *out = f.base + at;
     f.used = at + bytes;
     return VQA_OK;
+}
+
+int call_side_streams(const EvalCall& call, int want, hipStream_t* streams, hipEvent_t* done, hipEvent_t* fork) {
+    if (call.fixed || want <= 0) return 0;
+    DeviceState* ds;
+    if (device_state(call.device, &ds) != VQA_OK) return 0;
+    std::lock_guard<std::recursive_mutex> lk(ds->call_mu);
+    if (hipSetDevice(call.device) != hipSuccess) return 0;
+    if (!ds->side_fork && hipEventCreateWithFlags(&ds->side_fork, hipEventDisableTiming) != hipSuccess) return 0;
+    int got = 0;
+    for (; got < std::min(want, 3); ++got) {
+        if (!ds->side[got]) {
+            hipStream_t st = nullptr;
+            hipEvent_t ev = nullptr;
+            if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) break;
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+                (void)hipStreamDestroy(st);
+                break;
+            }
+            ds->side[got] = st;
+            ds->side_done[got] = ev;
+        }
+        streams[got] = ds->side[got];
+        done[got] = ds->side_done[got];
+    }
+    *fork = ds->side_fork;
+    return got;
 }
 
 size_t call_workspace_room(const EvalCall& call) {

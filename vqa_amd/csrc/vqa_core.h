@@ -228,5 +228,11 @@ size_t call_workspace_room(const EvalCall& call);
 // not allocate (pageable copies stage through buffers the runtime may allocate), chunks passed
 // as kernel arguments to a copy kernel.  d_dst 16-byte aligned, with room for bytes rounded up to 16.
 int call_upload(const EvalCall& call, void* d_dst, const void* src, size_t bytes);
+// Up to three more streams of the library's own on the call's device, for a call that spreads independent
+// work over several hardware queues, with an event each and one event to start them from.  The call makes
+// them wait for *fork (recorded on its own stream) before their first kernel and its own stream wait for
+// done[i] (recorded behind their last kernel) before it returns, so that the call's stream still orders the
+// whole call.  Returns how many it got (0 for a call that must not allocate).
+int call_side_streams(const EvalCall& call, int want, hipStream_t* streams, hipEvent_t* done, hipEvent_t* fork);
 
 }  // namespace vqa
