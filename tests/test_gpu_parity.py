@@ -457,13 +457,14 @@ def test_parameter_subset_sweep(n, d, builder):
     assert np.abs(eh[:, [0, 2 * mine[0] + 1, 2 * mine[1] + 2]] - full_e.cpu().numpy()[:, [0, 2 * mine[0] + 1, 2 * mine[1] + 2]]).max() < TOL
 
 
-@pytest.mark.parametrize("cap", [None, 30, 12])
+@pytest.mark.parametrize("cap", [None, 44, 30, 12])
 def test_streaming_sweep_in_chunks_with_late_branching(cap, monkeypatch):
     """IBM-HEA on 16 qubits, depth 3, on the HBM engine: the parameters' states branch off the running
     state at the first sweep of their pass they can change.  With the number of states in HBM capped
-    the sweep runs in several chunks of parameters, and chunks that branch in the same pass share its
-    branching points (cap 30); a cap that leaves no room for branching points runs the earlier form
-    (cap 12).  Every row against the oracle, and one sample's rows again from a sweep of two samples."""
+    the sweep runs in several chunks of parameters: with the branching points of all passes kept (left by
+    the sample's unshifted run, cap 44) or those of one pass at a time (left by a second unshifted state
+    that runs beside the chunks, which share them when they branch in the same pass, cap 30); a cap that
+    leaves no room for branching points runs the earlier form (cap 12).  Every row against the oracle, and one sample's rows again from a sweep of two samples."""
     n, d = 16, 3
     if cap is not None:
         monkeypatch.setenv("VQA_HBM_MAX_STATES", str(cap))

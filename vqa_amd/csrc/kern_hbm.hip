@@ -2337,10 +2337,14 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
     // pass that the parameter can change (ord_sweep).  The running state then runs the pass first and leaves
     // the tile as it is in front of every such sweep (one place per distinct sweep of the pass), and the
     // branching states start there instead of at the head of the pass.  Taken when it saves a tenth of
-    // the sweeps and the places cost at most a quarter of the parameter slots.
+    // the sweeps and the places cost at most a quarter of the parameter slots.  When there is room for the
+    // places of ALL passes at once, the run of the unshifted circuit that every sample starts with leaves
+    // them on its way and no second unshifted state runs beside the parameters' (keep_all).
     const size_t n_pass = plan.passes.size();
     std::vector<uint64_t> snap_mask(n_pass, 0);
+    std::vector<int> snap_base(n_pass, 0);   // keep_all: the first place of each pass
     int n_snap = 0;
+    bool keep_all = false;
     {
         int64_t total = 0, saved = 0;
         std::vector<int64_t> tail(n_pass + 1, 0);   // sweeps from pass k to the end
@@ -2350,9 +2354,19 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
             saved += ord_sweep[q];
             snap_mask[ord_pass[q]] |= (uint64_t)1 << ord_sweep[q];
         }
-        for (size_t k = 0; k < n_pass; ++k) n_snap = std::max(n_snap, __builtin_popcountll(snap_mask[k]));
-        const bool fits = Cmax - 3 - n_alt - n_snap >= std::min<int64_t>(m, 4 * (int64_t)n_snap);
-        if (m == 0 || saved * 10 < total || !fits || getenv("VQA_NO_LATE_BRANCH")) n_snap = 0;
+        int n_sum = 0;
+        for (size_t k = 0; k < n_pass; ++k) {
+            n_snap = std::max(n_snap, __builtin_popcountll(snap_mask[k]));
+            n_sum += __builtin_popcountll(snap_mask[k]);
+        }
+        auto fits = [&](int places) { return Cmax - 3 - n_alt - places >= std::min<int64_t>(m, 4 * (int64_t)places); };
+        if (m == 0 || saved * 10 < total || !fits(n_snap) || getenv("VQA_NO_LATE_BRANCH")) {
+            n_snap = 0;
+        } else if (fits(n_sum) && !getenv("VQA_LATE_BRANCH_PER_PASS")) {
+            keep_all = true;
+            n_snap = n_sum;
+            for (size_t k = 1; k < n_pass; ++k) snap_base[k] = snap_base[k - 1] + __builtin_popcountll(snap_mask[k - 1]);
+        }
     }
     const bool late = n_snap > 0;
     const int C = (int)std::min<int64_t>(Cmax - 3 - n_alt - n_snap, std::max(m, 1));
@@ -2419,7 +2433,7 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
     if (late) {
         for (int q = 0; q < m; ++q) {
             const uint64_t below = snap_mask[ord_pass[q]] & (((uint64_t)1 << ord_sweep[q]) - 1);
-            h_branch.push_back(BranchRec{ (int64_t)__builtin_popcountll(below) * D, ord_sweep[q], 0 });
+            h_branch.push_back(BranchRec{ (int64_t)(snap_base[ord_pass[q]] + __builtin_popcountll(below)) * D, ord_sweep[q], 0 });
         }
         VQA_HIP(hipMemcpyAsync(d_branch, h_branch.data(), (size_t)m * sizeof(BranchRec), hipMemcpyHostToDevice, call.stream));
     }
@@ -2481,7 +2495,16 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
         if (h.n_ops > 0)
             hipLaunchKernelGGL(k_angles, dim3((unsigned)((h.n_ops + kT - 1) / kT)), dim3(kT), 0, call.stream, h, tab);
         launch_mats(call, pd, tab, h.n_ops, 0, 1);
-        launch_all_passes(call, pd, F, 0, 1);
+        for (size_t k = 0; k < n_pass; ++k) {
+            PassIO io;
+            memset(&io, 0, sizeof(io));
+            io.alt_from = 1 << 30;
+            if (keep_all) {
+                io.snap_mask = snap_mask[k];
+                io.snap = snap + (int64_t)snap_base[k] * D;
+            }
+            launch_pass(call, pd, k, F, 0, 1, &io);
+        }
         rc = measure_states(call, F, 1, row0, nb, partial, nullptr, hl);   // leaves F alone: the layer goes onto hl.alt
         if (rc) return rc;
         if (fu.h_indep) {
@@ -2507,7 +2530,7 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
         }
         if (m == 0) continue;
         // the parameters, a chunk of slots at a time, in the order of the passes that hold their rotations
-        hipLaunchKernelGGL(k_init, dim3(gD), dim3(kT), 0, call.stream, R, D, D);
+        if (!keep_all) hipLaunchKernelGGL(k_init, dim3(gD), dim3(kT), 0, call.stream, R, D, D);
         double2* Rcur = R;
         size_t rpass = 0;
         for (int a = 0; a < m; a += C) {
@@ -2517,7 +2540,7 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
             hipLaunchKernelGGL(k_sweep_angles, dim3((unsigned)((na + kT - 1) / kT)), dim3(kT), 0, call.stream, h, j,
                                d_ord + a, cnt + 2, tab);
             launch_mats(call, pd, tab, h.n_ops, 0, cnt + 2);
-            for (; rpass < k0; ++rpass) launch_pass(call, pd, rpass, Rcur, 1, 1);
+            for (; !keep_all && rpass < k0; ++rpass) launch_pass(call, pd, rpass, Rcur, 1, 1);
             int live = 0;
             for (size_t k = k0; late && k < n_pass; ++k) {
                 // Late branching: the running state (in place, table row 1) runs pass k once, beside the chunk's
@@ -2529,7 +2552,7 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
                 PassIO io;
                 memset(&io, 0, sizeof(io));
                 io.alt_from = 1 << 30;
-                const bool run_r = rpass == k && (fresh > 0 || k < k1);
+                const bool run_r = !keep_all && rpass == k && (fresh > 0 || k < k1);
                 if (run_r) {
                     io.snap_mask = snap_mask[k];
                     io.snap = snap;
@@ -2538,7 +2561,7 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
                 PassIO bio;
                 memset(&bio, 0, sizeof(bio));
                 bio.alt_src = snap;
-                if (k < k1) {
+                if (!keep_all && k < k1) {
                     if (run_r) launch_pass(call, pd, k, R, 1, live + 1, &io);
                     else launch_pass(call, pd, k, S, 2, live, &io);
                     bio.alt_from = 0;
@@ -2600,8 +2623,9 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
     VQA_HIP(hipGetLastError());
     if (getenv("VQA_PLAN_DEBUG")) {
         fprintf(stderr, "[vqa] sweep of %d samples: %d live parameters, %zu passes, %lld state passes in all (%.1f per sample); "
-                "%d parameter slots per chunk, %d places for branching points, %d lanes\n",
-                n_samples, m, n_pass, (long long)t_state_passes, (double)t_state_passes / std::max(n_samples, 1), C, n_snap, n_lanes);
+                "%d parameter slots per chunk, %d places for branching points%s, %d lanes\n",
+                n_samples, m, n_pass, (long long)t_state_passes, (double)t_state_passes / std::max(n_samples, 1), C, n_snap,
+                keep_all ? " (all passes)" : "", n_lanes);
         for (size_t k = 0; k < n_pass; ++k) {
             const auto& p = plan.passes[k];
             int nb_ = 0, skip = 0;
