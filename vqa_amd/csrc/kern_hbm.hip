@@ -2492,9 +2492,18 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
         // the unshifted circuit: row 0 of the sample (NaN when the sample index is invalid)
         h.e_base = row0;
         hipLaunchKernelGGL(k_init, dim3(gD), dim3(kT), 0, call.stream, F, D, D);
-        if (h.n_ops > 0)
-            hipLaunchKernelGGL(k_angles, dim3((unsigned)((h.n_ops + kT - 1) / kT)), dim3(kT), 0, call.stream, h, tab);
-        launch_mats(call, pd, tab, h.n_ops, 0, 1);
+        if (m > 0) {
+            // the tables of the first chunk of parameters hold the unshifted circuit's in row 0
+            const int cnt = std::min(C, m);
+            const int64_t na = (int64_t)(cnt + 2) * h.n_ops;
+            hipLaunchKernelGGL(k_sweep_angles, dim3((unsigned)((na + kT - 1) / kT)), dim3(kT), 0, call.stream, h, j, d_ord,
+                               cnt + 2, tab);
+            launch_mats(call, pd, tab, h.n_ops, 0, cnt + 2);
+        } else {
+            if (h.n_ops > 0)
+                hipLaunchKernelGGL(k_angles, dim3((unsigned)((h.n_ops + kT - 1) / kT)), dim3(kT), 0, call.stream, h, tab);
+            launch_mats(call, pd, tab, h.n_ops, 0, 1);
+        }
         for (size_t k = 0; k < n_pass; ++k) {
             PassIO io;
             memset(&io, 0, sizeof(io));
@@ -2536,10 +2545,12 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
         for (int a = 0; a < m; a += C) {
             const int cnt = std::min(C, m - a);
             const size_t k0 = (size_t)ord_pass[a], k1 = (size_t)ord_pass[a + cnt - 1];
-            const int64_t na = (int64_t)(cnt + 2) * h.n_ops;
-            hipLaunchKernelGGL(k_sweep_angles, dim3((unsigned)((na + kT - 1) / kT)), dim3(kT), 0, call.stream, h, j,
-                               d_ord + a, cnt + 2, tab);
-            launch_mats(call, pd, tab, h.n_ops, 0, cnt + 2);
+            if (a > 0) {
+                const int64_t na = (int64_t)(cnt + 2) * h.n_ops;
+                hipLaunchKernelGGL(k_sweep_angles, dim3((unsigned)((na + kT - 1) / kT)), dim3(kT), 0, call.stream, h, j,
+                                   d_ord + a, cnt + 2, tab);
+                launch_mats(call, pd, tab, h.n_ops, 0, cnt + 2);
+            }
             for (; !keep_all && rpass < k0; ++rpass) launch_pass(call, pd, rpass, Rcur, 1, 1);
             int live = 0;
             for (size_t k = k0; late && k < n_pass; ++k) {
