@@ -400,11 +400,15 @@ def test_pauli_sum_ring_hamiltonian():
     assert np.abs(got - want).max() < 1e-9   # 32 terms of order one: absolute 1e-10 per term
 
 
+@pytest.mark.parametrize("tile12", [False, True])
 @pytest.mark.parametrize("n,d", [(14, 2), (15, 1)])
-def test_streaming_sweep_with_pauli_sums(n, d):
+def test_streaming_sweep_with_pauli_sums(n, d, tile12, monkeypatch):
     """Full sweeps on the HBM engine with several observables at once: Z-strings of different
     observables batched together, pure-X terms measured behind a Hadamard layer, mixed X/Y/Z
-    strings one by one; every instance against the oracle."""
+    strings one by one; every instance against the oracle.  Both builds of the tiled passes
+    (11- and 12-qubit tiles)."""
+    if tile12:
+        monkeypatch.setenv("VQA_TILE12", "1")
     c = create_ry_cz_ansatz(n, d, seed=4)
     rng = np.random.default_rng(n)
     theta = rng.uniform(-np.pi, np.pi, c.n_theta)
@@ -457,8 +461,9 @@ def test_parameter_subset_sweep(n, d, builder):
     assert np.abs(eh[:, [0, 2 * mine[0] + 1, 2 * mine[1] + 2]] - full_e.cpu().numpy()[:, [0, 2 * mine[0] + 1, 2 * mine[1] + 2]]).max() < TOL
 
 
+@pytest.mark.parametrize("tile12", [False, True])
 @pytest.mark.parametrize("cap", [None, 44, 30, 12])
-def test_streaming_sweep_in_chunks_with_late_branching(cap, monkeypatch):
+def test_streaming_sweep_in_chunks_with_late_branching(cap, tile12, monkeypatch):
     """IBM-HEA on 16 qubits, depth 3, on the HBM engine: the parameters' states branch off the running
     state at the first sweep of their pass they can change.  With the number of states in HBM capped
     the sweep runs in several chunks of parameters: with the branching points of all passes kept (left by
@@ -468,6 +473,8 @@ def test_streaming_sweep_in_chunks_with_late_branching(cap, monkeypatch):
     n, d = 16, 3
     if cap is not None:
         monkeypatch.setenv("VQA_HBM_MAX_STATES", str(cap))
+    if tile12:
+        monkeypatch.setenv("VQA_TILE12", "1")   # the build with 12-qubit tiles (the library's choice from 26 qubits on)
     c = create_ibm_HEA_ansatz(n, d, seed=2)
     rng = np.random.default_rng(16)
     theta = rng.uniform(0, 2 * np.pi, c.n_theta)
@@ -522,13 +529,16 @@ def _edge_circuit(n, shared):
     return c
 
 
+@pytest.mark.parametrize("tile12", [False, True])
 @pytest.mark.parametrize("shared", [False, True])
-def test_streaming_sweep_edge_cases(shared):
+def test_streaming_sweep_edge_cases(shared, tile12, monkeypatch):
     """The streaming engine's sweep (one moved state per parameter) on a circuit with scaled
     parameters and one that drives no gate; with a parameter shared by two gates the call is
     served by the explicit list.  A sample index beyond the batch gives NaN rows; an observable
     without terms gives zeros."""
     n = 14
+    if tile12:
+        monkeypatch.setenv("VQA_TILE12", "1")
     c = _edge_circuit(n, shared)
     rng = np.random.default_rng(17)
     theta = rng.uniform(-3, 3, c.n_theta)

@@ -32,6 +32,16 @@
 #define VQA_TILE_BITS 12
 #endif
 
+// The file is built twice with different tile shapes (Makefile): VQA_HBM_VARIANT is the suffix of this
+// build's four entry points, between which hbm_engine_run / _can_sweep / _sweep / _statevector
+// (vqa_abi.hip) choose by the register size.
+#ifndef VQA_HBM_VARIANT
+#define VQA_HBM_VARIANT _t12
+#endif
+#define VQA_HBM_CAT2(a, b) a##b
+#define VQA_HBM_CAT(a, b) VQA_HBM_CAT2(a, b)
+#define HBM_FN(name) VQA_HBM_CAT(name, VQA_HBM_VARIANT)
+
 namespace vqa {
 
 namespace {
@@ -2193,7 +2203,7 @@ struct Carver {
     size_t add(size_t bytes) { const size_t at = total; total += pad256(bytes); return at; }
 };
 
-int hbm_engine_run(const EvalCall& call) {
+int HBM_FN(hbm_engine_run)(const EvalCall& call) {
     const int n = call.c->n_qubits;
     if (n < 1 || n > 30) VQA_FAIL(VQA_EUNSUPPORTED, "HBM engine supports 1..30 qubits (got %d)", n);
     if (call.n_marg_bits > 10)
@@ -2258,13 +2268,13 @@ int hbm_engine_run(const EvalCall& call) {
     return VQA_OK;
 }
 
-bool hbm_engine_can_sweep(const EvalCall& call) {
+bool HBM_FN(hbm_engine_can_sweep)(const EvalCall& call) {
     if (!tiled(call) || !call.spec.psr || call.n_sweep <= 0 || call.c->n_theta == 0 || !call.cone) return false;
     return cone_plan_of(call).sweepable;
 }
 
 // Full parameter-shift sweeps of n_samples samples (rows j * (2P+1) + k of the outputs).
-int hbm_engine_sweep(const EvalCall& call, int n_samples) {
+int HBM_FN(hbm_engine_sweep)(const EvalCall& call, int n_samples) {
     const int n = call.c->n_qubits;
     if (n > 30) VQA_FAIL(VQA_EUNSUPPORTED, "HBM engine supports 1..30 qubits (got %d)", n);
     if (call.n_marg_bits > 10)
@@ -2656,7 +2666,7 @@ int hbm_engine_sweep(const EvalCall& call, int n_samples) {
     return VQA_OK;
 }
 
-int hbm_engine_statevector(const EvalCall& call, double* d_out_state) {
+int HBM_FN(hbm_engine_statevector)(const EvalCall& call, double* d_out_state) {
     const int n = call.c->n_qubits;
     if (n < 1 || n > 30) VQA_FAIL(VQA_EUNSUPPORTED, "HBM engine supports 1..30 qubits (got %d)", n);
     PlanDev pd;

@@ -116,6 +116,37 @@ static int workspace_get(int device, hipStream_t stream, size_t bytes, void** ou
     return VQA_OK;
 }
 
+// Which build of the tiled engine a circuit runs on.  11-qubit tiles from 13 to 25 qubits (below 13 nothing is
+// tiled and the builds do not differ).  From 26 qubits on it depends on what binds the passes: a deep circuit
+// (IBM-HEA, depth 8: some 20 non-diagonal gates per qubit, a dozen sweeps per pass) is bound by the work on the
+// tile and keeps the 11-qubit tiles (26 / 27 qubits: 3.5 against 3.0, 1.5 against 1.3 gradients/s); a shallow one
+// (RY + CZ ring, depth 6: 7 per qubit, 2-5 sweeps per pass) is bound by HBM and takes the 12-qubit tiles, which
+// need fewer passes over the state (28 qubits: 3.97 against 4.16 s per gradient).  VQA_TILE12=1: always the
+// latter.  Decided when a circuit first runs on the engine: its cached plans belong to one build.
+static bool small_tiles(const EvalCall& call) {
+    std::lock_guard<std::mutex> lk(call.c->mu);
+    if (call.c->hbm_tiles == 0) {
+        const int n = call.c->n_qubits;
+        int64_t dense = 0;
+        for (const vqa_op& op : call.c->ops)
+            dense += op.kind == VQA_GATE_H || op.kind == VQA_GATE_X || op.kind == VQA_GATE_Y || op.kind == VQA_GATE_RX ||
+                     op.kind == VQA_GATE_RY;
+        const bool small = n >= 13 && (n <= 25 || dense >= 12 * (int64_t)n);
+        call.c->hbm_tiles = (small && !getenv("VQA_TILE12")) ? 11 : 12;
+    }
+    return call.c->hbm_tiles == 11;
+}
+int hbm_engine_run(const EvalCall& call) { return small_tiles(call) ? hbm_engine_run_t11(call) : hbm_engine_run_t12(call); }
+bool hbm_engine_can_sweep(const EvalCall& call) {
+    return small_tiles(call) ? hbm_engine_can_sweep_t11(call) : hbm_engine_can_sweep_t12(call);
+}
+int hbm_engine_sweep(const EvalCall& call, int n_samples) {
+    return small_tiles(call) ? hbm_engine_sweep_t11(call, n_samples) : hbm_engine_sweep_t12(call, n_samples);
+}
+int hbm_engine_statevector(const EvalCall& call, double* d_out_state) {
+    return small_tiles(call) ? hbm_engine_statevector_t11(call, d_out_state) : hbm_engine_statevector_t12(call, d_out_state);
+}
+
 int call_workspace(const EvalCall& call, size_t bytes, void** out) {
     if (!call.fixed) return workspace_get(call.device, call.stream, bytes, out);
     FixedScratch& f = *call.fixed;

@@ -151,6 +151,7 @@ struct vqa_circuit {
     std::vector<vqa_op> ops;
     std::shared_ptr<vqa::RegProgram> reg;  // host copy of the engine-2 program (may be null)
     std::shared_ptr<void> hbm_plan;        // engine 3: the gate list cut into tiled passes (built on first use)
+    int hbm_tiles = 0;                     // engine 3: the build whose plans this circuit holds (11 or 12; 0: not chosen yet)
     std::map<uint64_t, std::shared_ptr<void>> hbm_hplans;   // engine 3: Hadamard layers used to measure X-type terms, by qubit mask
     std::map<std::pair<uint64_t, uint64_t>, std::shared_ptr<vqa::ConeInfo>> cones;   // by (Z-type, general) measured qubits
     std::mutex mu;
@@ -193,10 +194,21 @@ bool reg_engine_can_sweep(const RegProgram& prog);
 int reg_engine_sweep(const EvalCall& call, const void* d_prog, const RegProgram& prog, int n_samples);
 bool reg_engine_can_group(const RegProgram& prog);
 int reg_engine_group(const EvalCall& call, const void* d_prog, const RegProgram& prog, int n_samples);
+// engine 3 (kern_hbm.hip, built twice: 12-qubit tiles with four amplitude bits per thread, _t12, and
+// 11-qubit tiles with three, _t11, which keeps four workgroups on a CU instead of two and is 6-15 % faster
+// up to 24 qubits); these four choose the build by the register size (vqa_abi.hip)
 int hbm_engine_run(const EvalCall& call);
 bool hbm_engine_can_sweep(const EvalCall& call);
 int hbm_engine_sweep(const EvalCall& call, int n_samples);
 int hbm_engine_statevector(const EvalCall& call, double* d_out_state);
+int hbm_engine_run_t12(const EvalCall& call);
+bool hbm_engine_can_sweep_t12(const EvalCall& call);
+int hbm_engine_sweep_t12(const EvalCall& call, int n_samples);
+int hbm_engine_statevector_t12(const EvalCall& call, double* d_out_state);
+int hbm_engine_run_t11(const EvalCall& call);
+bool hbm_engine_can_sweep_t11(const EvalCall& call);
+int hbm_engine_sweep_t11(const EvalCall& call, int n_samples);
+int hbm_engine_statevector_t11(const EvalCall& call, double* d_out_state);
 
 // rows 2i+1, 2i+2 of every sample <- its row 0, for the parameters i of d_list (kern_sample.hip)
 int fill_dead_rows(hipStream_t stream, double* d_out, int64_t n_samples, int K, int stride, const int32_t* d_list, int n_list);
