@@ -1075,6 +1075,15 @@ static bool group_sweeps(TilePlan::Pass& pass, const std::vector<TileGate>& in_o
             tp.push_back(*it);   // every class keeps a position outside the group (fits())
             rest.erase(it);
         }
+        // A 16-byte LDS read serves the lanes in four groups of 16 that are not contiguous: lane bits 0 and 1
+        // and the even (or odd) patterns of bits 2, 3, 4.  With the classes 0, 1, 2, 3 on bits 0 .. 3 the 16
+        // lanes of such a group land in 16 different bank groups exactly when bit 4 gets a position of
+        // class 0 or 1 (the sums of the slot bits of lane bits 2 + 3 and 2 + 4 then complete bits 0 and 1);
+        // 16-byte writes go by 8 contiguous lanes, which the classes 0, 1, 2 on bits 0 .. 2 keep apart.
+        {
+            auto it = std::find_if(rest.begin(), rest.end(), [](int p) { return (p & 3) < 2; });
+            if (it != rest.end()) std::rotate(rest.begin(), it, it + 1);
+        }
         tp.insert(tp.end(), rest.begin(), rest.end());
         for (int j = 0; j < kGroup; ++j) sd.gpos[j] = hs.gpos[j];
         for (int b = 0; b < kThreadBits; ++b) sd.tpos[b] = tp[b];
