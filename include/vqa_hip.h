@@ -187,7 +187,10 @@ int vqa_eval_batch_dev(vqa_circuit* c, int device, void* stream,
  * per-device lock while it queues its work, and a call that takes the
  * workspace makes its stream wait for the previous user's last kernel (an
  * event), so such calls run one after the other on the GPU.  Different devices
- * are independent.
+ * are independent.  A sweep of several samples on the streaming engine may
+ * spread them over a few more streams of the library's own: they start behind
+ * an event on the caller's stream, and the caller's stream waits for them
+ * before the call returns, so the caller orders against `stream` alone.
  */
 int vqa_psr_full(vqa_circuit* c, int device,
                  const double* theta, const double* input_angles, int B,
