@@ -250,8 +250,7 @@ struct TilePassArgs {
     int tq[kTileBits];                        // tile position -> qubit (ascending)
     int oq[32];                               // outer bit number -> qubit (ascending)
     int n_outer;
-    int n_sweeps, first_run;                  // this pass
-    int first_xb, first_xt;                   // x_begin, x_tab of first_run
+    int n_sweeps;                             // this pass
     int n_ops_total, n_runs_total, n_x_total, n_sweeps_total; // row lengths of the per-instance tables
     int sweep_off;                            // where the pass's sweeps start in a row
 #ifdef VQA_TILE_ABLATE
@@ -965,8 +964,6 @@ struct TilePlan {
     std::vector<RunDesc> all_runs;
     std::vector<SweepDesc> all_sweeps;
     std::vector<size_t> soff;          // where each pass's sweeps start
-    std::vector<int> first_run;        // each pass's first diagonal run (plan numbering), -1: none
-    std::vector<int> first_xb, first_xt;   // and its late gates (x_begin, x_tab)
     std::vector<int> pass_of_gate;     // gate index -> the pass that runs it
     std::vector<int> first_sweep_of_gate;   // gate index -> the first sweep of that pass it can change (0 unless it sits in a fused 2x2)
     // parameter-shift sweeps (filled by plan_sweep): the parameters that drive exactly one
@@ -1279,7 +1276,6 @@ static TilePlan plan_tiles(int n, const std::vector<vqa_op>& ops, const std::vec
             plan.all_ops.push_back(op);
             plan.op_mat0.push_back(mbase);
         }
-        int first = -1;
         for (SweepDesc sd : p.sweeps) {
             sd.op_begin += obase;
             for (int j = 0; j < 4; ++j)
@@ -1288,17 +1284,7 @@ static TilePlan plan_tiles(int n, const std::vector<vqa_op>& ops, const std::vec
             if (sd.next_run >= 0) sd.next_run += rbase;
             sd.x_begin += xbase;
             sd.nx_begin += xbase;
-            if (first < 0 && sd.run >= 0) {
-                first = sd.run;
-                plan.first_xb.push_back(sd.x_begin);
-                plan.first_xt.push_back(sd.x_tab);
-            }
             plan.all_sweeps.push_back(sd);
-        }
-        plan.first_run.push_back(first);
-        if (first < 0) {
-            plan.first_xb.push_back(0);
-            plan.first_xt.push_back(0);
         }
     }
     return plan;
@@ -1851,9 +1837,6 @@ void launch_pass(const EvalCall& call, const PlanDev& pd, size_t k, double2* st,
     }
     for (int t = 0; t < kTileBits; ++t) a.tq[t] = p.tq[t];
     a.n_sweeps = (int)p.sweeps.size();
-    a.first_run = plan.first_run[k];
-    a.first_xb = plan.first_xb[k];
-    a.first_xt = plan.first_xt[k];
     a.n_ops_total = (int)pd.n_ops();
     a.n_runs_total = (int)pd.n_runs();
     a.n_x_total = (int)pd.n_x();
