@@ -199,8 +199,10 @@ struct GroupOp {
                                               // in front of the rotation (nothing earlier in the pass could take it); CNOT: a = control position
 };
 struct MatDesc {
-    int32_t begin, count;                     // gates [begin, begin + count) of the plan's gate image, multiplied in order
+    int32_t begin, count;                     // gates [begin, begin + count) of the plan's gate image, multiplied in order;
+                                              // count | kMatPlain: keep the three-shear form (A0 = A1 = 1 is counted on)
 };
+constexpr int32_t kMatPlain = 1 << 30;
 // a diagonal run: its gates inside the tile, except the two-qubit gates that join the halves
 struct RunDesc {
     int32_t g1_begin, g1_count;               // single-qubit gates in the plan's gate image
@@ -295,7 +297,7 @@ __global__ __launch_bounds__(kT) void k_mats(const TileGate* __restrict__ gates,
     const int ci = (int)(i / M), k = (int)(i - (int64_t)ci * M);
     const MatDesc md = descs[k];
     c2 m00 = { 1, 0 }, m01 = { 0, 0 }, m10 = { 0, 0 }, m11 = { 1, 0 };
-    for (int g = md.begin; g < md.begin + md.count; ++g) {
+    for (int g = md.begin; g < md.begin + (md.count & ~kMatPlain); ++g) {
         const TileGate tg = gates[g];
         const bool rot = tg.kind >= VQA_GATE_RX && tg.kind <= VQA_GATE_RZ;   // the others have no table entry to read
         const double2 cs = rot ? tab[(int64_t)ci * n_ops + tg.g] : make_double2(1.0, 0.0);
@@ -340,7 +342,7 @@ __global__ __launch_bounds__(kT) void k_mats(const TileGate* __restrict__ gates,
         }
     }
     double t = s / (1.0 + c), u = s;   // tan(phi / 2), sin(phi)
-    if (c >= 0.5) {
+    if (c >= 0.5 && !(md.count & kMatPlain)) {
         // two shears are enough up to the scales 1 / c and c, which A0 and A1 take over: a1 += (s / c) a0,
         // a0 -= (s c) a1.  (The first component comes out of a difference that leaves c^2 of it, so
         // the form is kept to angles where that costs two bits at most.)  Marked by a negative t.
@@ -1033,7 +1035,10 @@ static bool group_sweeps(TilePlan::Pass& pass, const std::vector<TileGate>& in_o
     for (const TileGate& tg : in_order) {
         if (tg.kind == kGateU) {
             const int p = tg.p0, mat = (int)pass.mats.size();
-            pass.mats.push_back(MatDesc{ (int)pass.gates.size(), (int)runs[tg.g].size() });
+            // A lone Hadamard (the layers that turn X factors into Z factors) is R(pi/4) diag(1, -1) exactly: in
+            // the three-shear form nothing is left behind the rotation, and its sweep needs no diagonal run for it.
+            const bool plain_h = runs[tg.g].size() == 1 && runs[tg.g][0].kind == VQA_GATE_H;
+            pass.mats.push_back(MatDesc{ (int)pass.gates.size(), (int)runs[tg.g].size() | (plain_h ? kMatPlain : 0) });
             for (TileGate e : runs[tg.g]) {
                 e.p0 = p;
                 pass.gates.push_back(e);
@@ -1044,7 +1049,7 @@ static bool group_sweeps(TilePlan::Pass& pass, const std::vector<TileGate>& in_o
             const int s = place(p, -1);   // (flushes the factor in front of the rotation, if any, to sweep last_flush)
             pass.mat_first.push_back(touched ? std::min(last_flush, s) : s);
             sweeps[s].ops.push_back(HOp{ OP_ROT, p, -1, mat, touched ? 0 : 1, {} });
-            pending.push_back(TileGate{ kGateD1A, p, -1, mat });
+            if (!plain_h) pending.push_back(TileGate{ kGateD1A, p, -1, mat });
         } else if (tg.kind == VQA_GATE_CNOT) {
             const int s = place(tg.p0, tg.p1);
             sweeps[s].ops.push_back(HOp{ OP_CNOT, tg.p0, tg.p1, -1, 0, tg });
@@ -1259,7 +1264,7 @@ static TilePlan plan_tiles(int n, const std::vector<vqa_op>& ops, const std::vec
                   rbase = (int)plan.all_runs.size(), xbase = (int)plan.all_xgates.size();
         for (const MatDesc& md : p.mats) plan.all_mats.push_back(MatDesc{ md.begin + gbase, md.count });
         for (size_t mi = 0; mi < p.mats.size(); ++mi)
-            for (int gi = p.mats[mi].begin; gi < p.mats[mi].begin + p.mats[mi].count; ++gi)
+            for (int gi = p.mats[mi].begin; gi < p.mats[mi].begin + (p.mats[mi].count & ~kMatPlain); ++gi)
                 plan.first_sweep_of_gate[p.gates[gi].g] = p.mat_first[mi];
         for (const RunDesc& rd : p.runs)
             plan.all_runs.push_back(RunDesc{ rd.g1_begin + gbase, rd.g1_count, rd.g2_begin + gbase, rd.g2_count });
