@@ -46,6 +46,35 @@ def random_circuit(cls, n, n_gates, seed, n_theta=5, n_input=3):
     return c
 
 
+def random_sweep_circuit(cls, n, n_gates, seed, n_theta=24, n_input=3):
+    """Random gate list in which every trainable parameter drives exactly one rotation (what a
+    parameter-shift sweep with one moved state per parameter takes), at random places among constant
+    gates of every kind, input rotations, lone CNOTs, CZs and CNOT - RZ - CNOT sandwiches."""
+    rng = np.random.default_rng(seed)
+    c = cls(n)
+    where = set(int(v) for v in rng.choice(n_gates, n_theta, replace=False))
+    for i in range(n_input):
+        getattr(c, f"add_input_R{'ZYX'[i % 3]}_gate")(int(rng.integers(n)), lambda x, i=i: x[i % len(x)] * (1 + 0.1 * i))
+    for g in range(n_gates):
+        q = int(rng.integers(n))
+        if g in where:
+            getattr(c, f"add_parametric_R{'XYZ'[int(rng.integers(3))]}_gate")(q, float(rng.uniform(0, 6.28)))
+            continue
+        k = int(rng.integers(12))
+        q1 = int((q + 1 + rng.integers(n - 1)) % n)
+        if k == 0: c.add_H_gate(q)
+        elif k == 1: getattr(c, f"add_{'XYZ'[int(rng.integers(3))]}_gate")(q)
+        elif k in (2, 3, 4): getattr(c, f"add_R{'XYZ'[k - 2]}_gate")(q, float(rng.uniform(-3, 3)))
+        elif k == 5: getattr(c, f"add_input_R{'XYZ'[int(rng.integers(3))]}_gate")(q, lambda x, q=q: x[q % len(x)] - 0.2)
+        elif k in (6, 7): c.add_CNOT_gate(q, q1)
+        elif k in (8, 9): c.add_CZ_gate(q, q1)
+        else:
+            c.add_CNOT_gate(q, q1)
+            c.add_input_RZ_gate(q1, lambda x, q=q, q1=q1: x[q % len(x)] * x[q1 % len(x)])
+            c.add_CNOT_gate(q, q1)
+    return c
+
+
 def random_observables(n, seed, n_obs=3, max_terms=4, xy=False):
     rng = np.random.default_rng(seed)
     out = []

@@ -495,6 +495,29 @@ def test_streaming_sweep_in_chunks_with_late_branching(cap, tile12, monkeypatch)
     assert np.abs(sub_e[:, rows] - got_e[:, rows]).max() < TOL and np.abs(sub_m[:, rows] - got_m[:, rows]).max() < TOL
 
 
+@pytest.mark.parametrize("tile12", [False, True])
+@pytest.mark.parametrize("n,seed", [(13, 1), (14, 2), (15, 3), (15, 4), (16, 5)])
+def test_streaming_sweep_random_circuits(n, seed, tile12, monkeypatch):
+    """Full sweeps of random circuits on the HBM engine (tiled passes with lone CNOTs, constant and input
+    gates of every kind between the parameters' rotations, which makes the parameters branch at many
+    different sweeps), both tile shapes; every row of two samples against the oracle."""
+    from helpers import random_sweep_circuit
+    if tile12:
+        monkeypatch.setenv("VQA_TILE12", "1")
+    set_engine("hbm")
+    c = random_sweep_circuit(LearningCircuit, n, 90, seed=seed)
+    rng = np.random.default_rng(seed)
+    theta = rng.uniform(-3, 3, c.n_theta)
+    x = rng.uniform(-1, 1, (2, 3))
+    ia = c.input_angles(x)
+    obs = random_observables(n, seed=seed, n_obs=2, max_terms=3)
+    si, sp, sv = cpu_oracle.psr_lists(2, c.n_theta)
+    want_e, want_m = cpu_oracle.eval_batch(c, theta, ia, si, sp, sv, obs_list=obs_tuples(obs), n_marg_bits=2)
+    got_e, got_m = c.psr_full(theta, ia, obs_list=obs, n_marg_bits=2)
+    assert np.abs(np.asarray(got_e).reshape(want_e.shape) - want_e).max() < TOL
+    assert np.abs(np.asarray(got_m).reshape(want_m.shape) - want_m).max() < TOL
+
+
 def _edge_circuit(n, shared):
     """Parameters with a coefficient, a parameter that drives no gate, (optionally) one shared by two
     gates, CNOT sandwiches, input gates, rotations of every axis on low, middle and top qubits."""
