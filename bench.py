@@ -402,6 +402,13 @@ def other_configs(device):
         K = 2 * c.n_theta + 1
         out[name] = {"gradients_per_sec": B / dt, "circuit_evals_per_sec": B * K / dt, "n_params": c.n_theta,
                      "ms_per_call": 1e3 * dt}
+        if n == 20:
+            # FP64 flops the tiled passes execute per sample of this configuration (PMC SQ_INSTS_VALU_{FMA,MUL,ADD}_F64 of
+            # tools/bench_hbm_batch.py 20 8 16, 11-qubit tiles) at the rate measured here, against the vector FP64 peak
+            flops = 8.96e10
+            out[name]["roofline"] = {"kernel": "k_tile_pass", "bound": "valu_fp64", "achieved": flops * B / dt / 1e12, "peak": 78.6,
+                                     "unit": "TFLOP/s", "frac": flops * B / dt / 78.6e12,
+                                     "executed_fp64_flops_per_sample": flops, "profile_source": "prof_r02f (PMC)"}
         del c, x
         torch.cuda.empty_cache()
     out["28-qubit VQE: RY + CZ ring depth 6, Ising ring (56 Pauli terms), full gradient"] = vqe_config(device)
@@ -459,8 +466,15 @@ def vqe_config(device, n=28, d=6):
         times.append(time.perf_counter() - t0)
     del vqe, c
     torch.cuda.empty_cache()
-    return {"seconds_per_gradient": times[1], "first_call_seconds": times[0], "n_params": int(len(theta)),
-            "shifted_evaluations_per_sec": 2 * len(theta) / times[1], "grad_norm": float(np.linalg.norm(g))}
+    res = {"seconds_per_gradient": times[1], "first_call_seconds": times[0], "n_params": int(len(theta)),
+           "shifted_evaluations_per_sec": 2 * len(theta) / times[1], "grad_norm": float(np.linalg.norm(g))}
+    if n == 28 and d == 6:
+        # passes over a state that one gradient makes (the library's own count, VQA_PLAN_DEBUG: 1211 that read and write a
+        # state, 588 measuring ones that only read) x 16 bytes x 2^28 amplitudes, against the 8 TB/s of HBM
+        nbytes = (1211 * 2 + 588) * 16.0 * 2 ** 28
+        res["roofline"] = {"kernel": "k_tile_pass", "bound": "hbm", "achieved": nbytes / times[1] / 1e9, "peak": 8000.0, "unit": "GB/s",
+                           "frac": nbytes / times[1] / 8e12, "bytes_per_gradient": nbytes}
+    return res
 
 
 def cpu_baseline(circ, theta, ia, P, seconds):
