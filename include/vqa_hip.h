@@ -219,7 +219,10 @@ int vqa_psr_full_dev(vqa_circuit* c, int device, void* stream,
  * VQA_EUNSUPPORTED with the sizes in the message (14 qubits: up to about 120 diagonal stages).
  * The sweep launches as many workgroups as the array has areas for, so large circuits run on a
  * part of the GPU: this entry point trades speed for the guarantee.  All calls on one GPU share
- * that GPU's array: calls that overlap in time on one GPU race; order them on one stream.
+ * that GPU's array: calls that overlap in time on one GPU race; order them on one stream.  On the
+ * host the call holds the same per-device lock as every other entry point while it queues its
+ * work (a static mutex: taking it allocates nothing), so host threads cannot interleave their
+ * launches; the lock does not order what runs on the GPU.
  */
 #define VQA_NOALLOC_SCRATCH_BYTES ((size_t)32 << 20)
 int vqa_psr_full_noalloc_dev(vqa_circuit* c, int device, void* stream,

@@ -356,7 +356,15 @@ def test_save_to_file_roundtrip(tmp_path):
     res = q.fit(options=dict(max_iter=2), auto_save=True, save_directory=str(tmp_path))
     files = list(tmp_path.iterdir())
     assert len(files) == 1
+    import dill   # what the reference's load_from_file reads the file with (myQNNs_base.py:499)
+
     with open(files[0], "rb") as f:
-        data = pickle.load(f)
+        data = dill.load(f)
     assert np.allclose(data["results"]["para_evol"][-1], res["para_evol"][-1])
     assert data["object"].n_params == q.n_params
+    # ... and this package's own loader: the saved object's state comes back into a fresh instance
+    q2, _ = small_regressor()
+    q2.load_from_file(files[0].name, directory=str(tmp_path))
+    assert q2._optimized and np.allclose(q2.model_params, res["para_evol"][-1])
+    assert np.allclose(q2.latest_results["para_evol"][-1], res["para_evol"][-1])
+    assert np.allclose(q2.exact_predict(q2.x_train), q.exact_predict(q.x_train))

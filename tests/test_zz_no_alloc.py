@@ -16,7 +16,7 @@ from vqa_amd.qml_utils import create_ibm_HEA_ansatz, create_jerbi_ansatz
 pytestmark = pytest.mark.gpu
 
 
-def sweep(entry, c, theta, x, sel, obs, n_marg_bits):
+def sweep(entry, c, theta, x, sel, obs, n_marg_bits, check_free=None):
     import torch
 
     dev = f"cuda:{c.device}"
@@ -32,6 +32,9 @@ def sweep(entry, c, theta, x, sel, obs, n_marg_bits):
     _lib.check(getattr(_lib.lib(), entry)(c.handle(), c.device, C.c_void_p(st), p(th), p(x), int(x.shape[0]), p(se), n_sel,
                                            0.5 * np.pi, oarr, n_obs, n_marg_bits, p(oe), p(om)))
     torch.cuda.synchronize()
+    if check_free is not None:
+        # (measured right behind the call, before torch copies the outputs anywhere)
+        assert torch.cuda.mem_get_info(c.device)[0] == check_free, "the allocation-free entry point changed the free memory"
     return oe.cpu().numpy(), None if om is None else om.cpu().numpy()
 
 
@@ -61,6 +64,13 @@ def test_noalloc_sweep_matches_the_allocating_entry_point(first, second):
         for mb in (2, 0):
             we, wm = sweep("vqa_psr_full_dev", c, theta, x, sel, obs, mb)
             ge, gm = sweep("vqa_psr_full_noalloc_dev", c, theta, x, sel, obs, mb)
+            # a repeat of the call (everything it could have created lazily exists now) must leave the
+            # device's free memory as it found it: the entry point allocates nothing
+            import torch
+            torch.cuda.synchronize()
+            free0 = torch.cuda.mem_get_info(c.device)[0]
+            ge2, _ = sweep("vqa_psr_full_noalloc_dev", c, theta, x, sel, obs, mb, check_free=free0)
+            assert np.array_equal(ge2, ge) or np.abs(ge2 - ge).max() < 1e-12
             assert not np.isnan(ge).any()
             assert np.abs(ge - we).max() < 1e-12
             if mb:

@@ -2182,6 +2182,8 @@ static int chunk_plan(const EvalCall& call, double frac, size_t cap_bytes, int64
     const int64_t D = (int64_t)1 << n;
     size_t free_b = 0, total_b = 0;
     VQA_HIP(hipMemGetInfo(&free_b, &total_b));
+    // (the workspace the library holds already is reused by this call: it counts as free)
+    free_b += call_workspace_held(call);
     // state budget: a share of what is free now
     size_t budget = std::min<size_t>(cap_bytes, (size_t)(frac * (double)free_b));
     Cmax = (int64_t)(budget / ((size_t)D * sizeof(double2)));
@@ -2417,7 +2419,7 @@ int HBM_FN(hbm_engine_sweep)(const EvalCall& call, int n_samples) {
     double* d_coef = (double*)(w + o_coef);
     int32_t* d_unused = (int32_t*)(w + o_unused);
     BranchRec* d_branch = (BranchRec*)(w + o_branch);
-    std::vector<BranchRec> h_branch;   // (the copy below has read it when hipMemcpyAsync returns: pageable memory)
+    std::vector<BranchRec> h_branch;   // (function-local: uploaded as kernel arguments, read before the upload returns)
     pd.buf = w + o_gate;
     pd.carve(w + o_inst, C + 2);
     rc = upload_plan(call, pd);
@@ -2442,7 +2444,9 @@ int HBM_FN(hbm_engine_sweep)(const EvalCall& call, int n_samples) {
             const uint64_t below = snap_mask[ord_pass[q]] & (((uint64_t)1 << ord_sweep[q]) - 1);
             h_branch.push_back(BranchRec{ (int64_t)(snap_base[ord_pass[q]] + __builtin_popcountll(below)) * D, ord_sweep[q], 0 });
         }
-        VQA_HIP(hipMemcpyAsync(d_branch, h_branch.data(), (size_t)m * sizeof(BranchRec), hipMemcpyHostToDevice, call.stream));
+        static_assert(sizeof(BranchRec) % 16 == 0, "upload_by_value writes whole 16-byte words");
+        rc = upload_by_value(call.stream, d_branch, h_branch.data(), (size_t)m * sizeof(BranchRec));
+        if (rc) return rc;
     }
     const unsigned gD = (unsigned)((D + kT - 1) / kT);
     // (on every way out the call's stream waits for the other lanes: it orders the workspace's next user)

@@ -194,12 +194,24 @@ __global__ __launch_bounds__(kT) void k_mse_stats(StatsArgs a) {
 }
 
 // out[c, k] = sum over tiles (in order) of partial[tile, c, k]
-__global__ __launch_bounds__(kT) void k_mse_stats_finish(const double* partial, int n_tiles, int n_rows, double* out) {
-    const int idx = blockIdx.x * kT + threadIdx.x;
-    if (idx >= n_rows * kQ) return;
+// Sums the tiles' partial results: out[idx] = sum over tiles, idx = (row, quantity).  A workgroup takes 16
+// consecutive idx (128-byte reads) and deals the tiles to 16 groups of threads; each thread adds its
+// tiles in ascending order and the 16 group sums meet in LDS in a fixed tree, so the result does not
+// depend on timing (it does differ in the last bits from a single ascending sum).
+__global__ __launch_bounds__(256) void k_mse_stats_finish(const double* partial, int n_tiles, int n_rows, double* out) {
+    __shared__ double red[16][17];
+    const int i = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int n = n_rows * kQ, idx = blockIdx.x * 16 + i;
     double s = 0.0;
-    for (int t = 0; t < n_tiles; ++t) s += partial[(size_t)t * n_rows * kQ + idx];
-    out[idx] = s;
+    if (idx < n)
+        for (int t = g; t < n_tiles; t += 16) s += partial[(size_t)t * n + idx];
+    red[g][i] = s;
+    __syncthreads();
+    for (int half = 8; half >= 1; half >>= 1) {
+        if (g < half) red[g][i] += red[g + half][i];
+        __syncthreads();
+    }
+    if (g == 0 && idx < n) out[idx] = red[0][i];
 }
 
 // ---- independent random allocation (gCANS / Refoqus): MSE_iEval_iRandom ---------------------------
@@ -371,7 +383,7 @@ int mse_stats_launch(hipStream_t stream, const double* d_E, const double* d_est,
     hipLaunchKernelGGL(k_mse_stats, dim3((unsigned)tiles), dim3(kT), 0, stream, a);
     VQA_HIP(hipGetLastError());
     const int n = (P + 1) * kQ;
-    hipLaunchKernelGGL(k_mse_stats_finish, dim3((unsigned)((n + kT - 1) / kT)), dim3(kT), 0, stream, d_workspace, (int)tiles,
+    hipLaunchKernelGGL(k_mse_stats_finish, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, stream, d_workspace, (int)tiles,
                        P + 1, d_out);
     VQA_HIP(hipGetLastError());
     return VQA_OK;

@@ -34,7 +34,7 @@ struct DeviceState {
     hipStream_t stream = nullptr;
     void* ws = nullptr;
     size_t ws_bytes = 0;
-    std::recursive_mutex call_mu;     // held while a call queues its work
+    std::recursive_mutex* call_mu = nullptr;   // held while a call queues its work (g_call_mu[device])
     hipEvent_t ws_event = nullptr;    // recorded behind the last user of the workspace
     hipStream_t ws_stream = nullptr;  // that user's stream
     bool ws_recorded = false;
@@ -46,6 +46,10 @@ struct DeviceState {
 };
 static std::mutex g_dev_mu;
 static std::map<int, std::unique_ptr<DeviceState>> g_dev;
+// One lock per device number, static so that taking it allocates nothing and needs no DeviceState:
+// the allocation-free entry point orders its launches against every other call with it.
+constexpr int kMaxDevices = 64;
+static std::recursive_mutex g_call_mu[kMaxDevices];
 
 static int device_state(int device, DeviceState** out) {
     std::lock_guard<std::mutex> lk(g_dev_mu);
@@ -53,10 +57,11 @@ static int device_state(int device, DeviceState** out) {
     if (it == g_dev.end()) {
         int count = 0;
         VQA_HIP(hipGetDeviceCount(&count));
-        if (device < 0 || device >= count)
+        if (device < 0 || device >= count || device >= kMaxDevices)
             VQA_FAIL(VQA_ENODEVICE, "device %d out of range (%d visible)", device, count);
         VQA_HIP(hipSetDevice(device));
         std::unique_ptr<DeviceState> ds(new DeviceState());
+        ds->call_mu = &g_call_mu[device];
         VQA_HIP(hipStreamCreateWithFlags(&ds->stream, hipStreamNonBlocking));
         VQA_HIP(hipEventCreateWithFlags(&ds->ws_event, hipEventDisableTiming));
         it = g_dev.emplace(device, std::move(ds)).first;
@@ -73,7 +78,7 @@ struct DeviceGuard {
         DeviceState* d;
         int rc = device_state(device, &d);
         if (rc) return rc;
-        d->call_mu.lock();
+        d->call_mu->lock();
         ds = d;
         return VQA_OK;
     }
@@ -86,7 +91,7 @@ struct DeviceGuard {
                 ds->ws_stream = ds->touch_stream;
             }
         }
-        ds->call_mu.unlock();
+        ds->call_mu->unlock();
     }
 };
 
@@ -94,7 +99,7 @@ static int workspace_get(int device, hipStream_t stream, size_t bytes, void** ou
     DeviceState* ds;
     int rc = device_state(device, &ds);
     if (rc) return rc;
-    std::lock_guard<std::recursive_mutex> lk(ds->call_mu);
+    std::lock_guard<std::recursive_mutex> lk(*ds->call_mu);
     VQA_HIP(hipSetDevice(device));
     if (ds->ws_bytes < bytes) {
         if (ds->ws) {
@@ -163,7 +168,7 @@ int call_side_streams(const EvalCall& call, int want, hipStream_t* streams, hipE
     if (call.fixed || want <= 0) return 0;
     DeviceState* ds;
     if (device_state(call.device, &ds) != VQA_OK) return 0;
-    std::lock_guard<std::recursive_mutex> lk(ds->call_mu);
+    std::lock_guard<std::recursive_mutex> lk(*ds->call_mu);
     if (hipSetDevice(call.device) != hipSuccess) return 0;
     if (!ds->side_fork && hipEventCreateWithFlags(&ds->side_fork, hipEventDisableTiming) != hipSuccess) return 0;
     int got = 0;
@@ -192,6 +197,14 @@ size_t call_workspace_room(const EvalCall& call) {
     return at > call.fixed->bytes ? 0 : call.fixed->bytes - at;
 }
 
+size_t call_workspace_held(const EvalCall& call) {
+    if (call.fixed) return 0;
+    DeviceState* ds;
+    if (device_state(call.device, &ds) != VQA_OK) return 0;
+    std::lock_guard<std::recursive_mutex> lk(*ds->call_mu);
+    return ds->ws_bytes;
+}
+
 // copy kernel of call_upload: the bytes travel as a kernel argument
 struct UploadChunk {
     uint4 v[192];   // 3 KiB of the 4 KiB a kernel's arguments may take
@@ -200,20 +213,24 @@ __global__ void k_upload(UploadChunk c, uint4* dst, int n16) {
     if ((int)threadIdx.x < n16) dst[threadIdx.x] = c.v[threadIdx.x];
 }
 
-int call_upload(const EvalCall& call, void* d_dst, const void* src, size_t bytes) {
-    if (!call.fixed) {
-        if (bytes) VQA_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, call.stream));
-        return VQA_OK;
-    }
+int upload_by_value(hipStream_t stream, void* d_dst, const void* src, size_t bytes) {
     for (size_t off = 0; off < bytes; off += sizeof(UploadChunk)) {
         UploadChunk c;
         const size_t nb = std::min(sizeof(UploadChunk), bytes - off);
         memset(&c, 0, sizeof(c));
         memcpy(&c, (const char*)src + off, nb);
-        hipLaunchKernelGGL(k_upload, dim3(1), dim3(192), 0, call.stream, c, (uint4*)((char*)d_dst + off), (int)((nb + 15) / 16));
+        hipLaunchKernelGGL(k_upload, dim3(1), dim3(192), 0, stream, c, (uint4*)((char*)d_dst + off), (int)((nb + 15) / 16));
     }
     VQA_HIP(hipGetLastError());
     return VQA_OK;
+}
+
+int call_upload(const EvalCall& call, void* d_dst, const void* src, size_t bytes) {
+    if (!call.fixed) {
+        if (bytes) VQA_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, call.stream));
+        return VQA_OK;
+    }
+    return upload_by_value(call.stream, d_dst, src, bytes);
 }
 
 // ---- circuit helpers ---------------------------------------------------------
@@ -753,7 +770,7 @@ int vqa_psr_full(vqa_circuit* c, int device, const double* theta, const double* 
 // Every GPU the library runs on holds its own copy until the process ends.  (Size:
 // VQA_NOALLOC_SCRATCH_BYTES of include/vqa_hip.h.)
 static __device__ __align__(256) unsigned char scratch[VQA_NOALLOC_SCRATCH_BYTES];
-constexpr int kMaxScratchDevices = 64;
+constexpr int kMaxScratchDevices = kMaxDevices;
 static std::mutex g_scratch_mu;
 static void* g_scratch_ptr[kMaxScratchDevices];   // device address of `scratch` on each GPU (null: not asked yet)
 
@@ -788,6 +805,9 @@ int vqa_psr_full_noalloc_dev(vqa_circuit* c, int device, void* stream, const dou
     VQA_HIP(hipGetDeviceCount(&count));
     if (device < 0 || device >= count || device >= kMaxScratchDevices)
         VQA_FAIL(VQA_ENODEVICE, "device %d out of range (%d visible)", device, count);
+    // the device's lock for the time the call queues its work, like every other entry point (a static
+    // mutex: nothing is allocated); what runs on the GPU is ordered by the caller's streams alone
+    std::lock_guard<std::recursive_mutex> device_lock(g_call_mu[device]);
     VQA_HIP(hipSetDevice(device));
     void* base = nullptr;
     if ((rc = scratch_address(device, &base))) return rc;

@@ -236,10 +236,15 @@ int irandom_stats_launch(hipStream_t stream, const double* d_expect, int n_obs, 
 int call_workspace(const EvalCall& call, size_t bytes, void** out);
 // bytes a call may still ask for: SIZE_MAX for the growable workspace
 size_t call_workspace_room(const EvalCall& call);
+// bytes of the growable workspace the library holds on the call's device right now (0 for a fixed region)
+size_t call_workspace_held(const EvalCall& call);
 // host -> device copy of a small table on the call's stream: hipMemcpyAsync, or, for a call that must
 // not allocate (pageable copies stage through buffers the runtime may allocate), chunks passed
 // as kernel arguments to a copy kernel.  d_dst 16-byte aligned, with room for bytes rounded up to 16.
 int call_upload(const EvalCall& call, void* d_dst, const void* src, size_t bytes);
+// the second form on its own: the source has been read when the function returns, whatever memory it is
+// in (a function-local table that must not outlive the call).  Same alignment and room as above.
+int upload_by_value(hipStream_t stream, void* d_dst, const void* src, size_t bytes);
 // Up to three more streams of the library's own on the call's device, for a call that spreads independent
 // work over several hardware queues, with an event each and one event to start them from.  The call makes
 // them wait for *fork (recorded on its own stream) before their first kernel and its own stream wait for

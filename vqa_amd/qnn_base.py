@@ -31,6 +31,11 @@ from __future__ import annotations
 import copy
 import os
 import pickle
+
+try:  # the reference writes and reads its files with dill (myQNNs_base.py:443, 499): same format when it is there
+    import dill as _serializer
+except ImportError:  # plain pickle streams are a subset of what dill reads
+    _serializer = pickle
 import uuid
 from typing import Optional
 
@@ -217,7 +222,9 @@ class myQNN_base:
         return results
 
     def save_to_file(self, results=None, save_self_obj=True, directory=None):
-        """myQNNs_base.py:404-451 with pickle; device handles are dropped by __getstate__."""
+        """myQNNs_base.py:404-451.  Written with dill when it is importable (the reference's
+        load_from_file reads such a file), else with pickle; device handles are dropped by
+        __getstate__ and come back on first use."""
         name = f"{self.id_string}_model_{getattr(self, '_optimizer_name', 'none')}_{self.file_id}.pkl"
         if directory:
             os.makedirs(directory, exist_ok=True)
@@ -227,14 +234,34 @@ class myQNN_base:
             try:
                 shadow = copy.copy(self)
                 shadow.__dict__.pop("optimizer", None)
-                shadow.circuit = None  # input_func lambdas do not pickle; the circuit is rebuilt by its builder
-                pickle.dumps(shadow)
+                if _serializer is pickle:
+                    shadow.circuit = None  # input_func lambdas do not pickle; the circuit is rebuilt by its builder
+                _serializer.dumps(shadow)
                 data["object"] = shadow
             except Exception as e:  # same policy as the reference: fall back to the results
                 print(f"An error occurred while saving self object: {e}")
         with open(name, "wb") as f:
-            pickle.dump(data, f)
+            _serializer.dump(data, f)
         return name
+
+    def load_from_file(self, filename, directory="."):
+        """myQNNs_base.py:473-507: a saved object replaces this instance's state (the circuit stays
+        when the file holds none), saved results alone go to latest_results."""
+        try:
+            with open(os.path.join(directory, filename), "rb") as f:
+                loaded = _serializer.load(f)
+            if "object" in loaded:
+                state = dict(loaded["object"].__dict__)
+                if state.get("circuit") is None:
+                    state.pop("circuit", None)
+                self.__dict__.update(state)
+                print(f"Self object updated from the file: {filename}")
+            if loaded.get("results") is not None:
+                self.latest_results = loaded["results"]
+                if "object" not in loaded:
+                    print(f"Results loaded into 'latest_results' from the file: {filename}")
+        except Exception as e:
+            print(f"An error occurred while loading data from file: {e}")
 
     # ---- batched circuit evaluation ------------------------------------------------
     def _obs_list(self):
