@@ -41,6 +41,11 @@ namespace vqa {
 // phase loop of shifted evaluations; 9: run the two shifts one by one instead of as a pair;
 // 10: pair measurement without loading the unshifted state; 11: without its reductions.
 // waves per SIMD the sweep kernel is register-budgeted for
+// Timing experiments on the sweep kernel (make libvqahip_var.so VAR_FLAGS=-DVQA_EXP=<bits>; results are
+// wrong on purpose): 1 no checkpoint loads, 2 no loads of the unshifted state in the pair measurement, 4 no
+// phase loop in the runs, 8 no measurement in the runs, 16 no late correction, 32 no record prefetch;
+// inside the phase loop: 64 no barriers in the transpositions, 128 no transpositions, 256 no register-bit
+// rotations, 512 no DPP lane rotations, 1024 no matrix-unit lane rotations, 2048 no diagonal stages.
 #ifndef VQA_EXP
 #define VQA_EXP 0
 #endif
@@ -48,6 +53,10 @@ namespace vqa {
 #define VQA_WAVES 3
 #endif
 // the same for the sweep kernel's one- and two-wave workgroups (10 and 11 qubits)
+// ... and for the sweep kernel that runs two runs side by side
+#ifndef VQA_PSR2_WAVES
+#define VQA_PSR2_WAVES 2
+#endif
 #ifndef VQA_SMALL_WAVES
 #define VQA_SMALL_WAVES 3
 #endif
@@ -97,6 +106,7 @@ struct RegArgs {
     int n_live;
     int need_psi;      // grouped sweeps: the list holds pair runs (the unshifted state of every sample is kept)
     int split;         // sweep kernel: workgroups that share a sample's run list (>= 1)
+    int use_ftab;      // sweep kernel: the diagonal stages' thread-factor tables are kept in LDS
 #ifdef VQA_PROF
     int ablate;
 #endif
@@ -273,7 +283,12 @@ __device__ __forceinline__ void uentry_product(const Prog& pp, int u, const doub
     }
 }
 
-template <bool SCALED>
+// TWO: a rotation on a register bit whose cos is at least kTwoShearMin and that has a diagonal stage behind it
+// is applied as TWO shears, R = diag(c, 1/c) L(-s c) U(s / c): the entry is (s / c, -s c) -- the sign bit of
+// the second number tells the forms apart -- and the scales go into the stage's phase slot with A, which
+// then has modulus c: a slot P stands for the factor P on |0> and conj(P) / |P|^2 on |1>.
+constexpr double kTwoShearMin = 0.25;
+template <bool SCALED, bool TWO = false>
 __device__ __forceinline__ void compute_uentry(const Prog& pp, int u, const double* theta, const double* row,
                                                int sparam, double sval, int pparam, double2& m, cplx& A, cplx& G,
                                                cplx& gp) {
@@ -302,7 +317,12 @@ __device__ __forceinline__ void compute_uentry(const Prog& pp, int u, const doub
     gp = cconj(eid);
     if (pp.uent[u].d_before < 0) gp = cmul(gp, G);
     if (!pp.uent[u].on_lane) {
-        m = make_double2(sn / (1.0 + c), sn);
+        if (TWO && c >= kTwoShearMin && pp.uent[u].d_after >= 0) {
+            m = make_double2(sn / c, -(sn * c));
+            A = { A.x * c, A.y * c };
+        } else {
+            m = make_double2(sn / (1.0 + c), sn);
+        }
     } else if (!SCALED || pp.uent[u].on_lane == 2) {   // (2: rotated by the matrix unit, exact form)
         m = make_double2(c, sn);
     } else if (c >= sn) {
@@ -325,7 +345,7 @@ __device__ __forceinline__ void compute_uentry(const Prog& pp, int u, const doub
 // computation for its few uncached lanes anyway): the input-dependent entries are computed,
 // the input-free ones copied, and an instance whose shift touches an input-free entry
 // recomputes that one entry and corrects the phase slots around it.
-template <bool SWEEP, bool SCALED>
+template <bool SWEEP, bool SCALED, bool TWO = false>
 __device__ __forceinline__ void prep_tables(const RegArgs& a, const Prog& pp, double2* tabs, int64_t e0, int S,
                                             int NU, int N1, int N2, int tid, int nthr, const double2* ctab = nullptr) {
     const int tab_stride = NU + N1 + N2;
@@ -399,7 +419,7 @@ __device__ __forceinline__ void prep_tables(const RegArgs& a, const Prog& pp, do
             const double* row = a.input + (size_t)b * a.n_input;
             double2 cs;
             cplx A, G, gp;
-            compute_uentry<SCALED>(pp, u, a.theta, row, sparam, sval, -1, cs, A, G, gp);
+            compute_uentry<SCALED, TWO>(pp, u, a.theta, row, sparam, sval, -1, cs, A, G, gp);
             double2* tb = tabs + (size_t)s2 * tab_stride;
             tb[u] = cs;
             if (d_before >= 0) {
@@ -493,6 +513,14 @@ __device__ __forceinline__ void rot_quad(double& a0, double& a1, double& b0, dou
         : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "+v"(c0), "+v"(c1), "+v"(d0), "+v"(d1)
         : "v"(u), "v"(s));
 }
+//   (a0, a1) <- (a0 + t a1, a1 + y (a0 + t a1)): the two-shear form (see compute_uentry), four pairs at once
+__device__ __forceinline__ void rot2_quad(double& a0, double& a1, double& b0, double& b1, double& c0, double& c1,
+                                          double& d0, double& d1, double t, double y) {
+    asm("v_fma_f64 %0, %8, %1, %0\n\tv_fma_f64 %2, %8, %3, %2\n\tv_fma_f64 %4, %8, %5, %4\n\tv_fma_f64 %6, %8, %7, %6\n\t"
+        "v_fma_f64 %1, %9, %0, %1\n\tv_fma_f64 %3, %9, %2, %3\n\tv_fma_f64 %5, %9, %4, %5\n\tv_fma_f64 %7, %9, %6, %7"
+        : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "+v"(c0), "+v"(c1), "+v"(d0), "+v"(d1)
+        : "v"(t), "v"(y));
+}
 //   x <- c x + se p
 __device__ __forceinline__ void lane_upd(double& x, double p, double c, double se) {
     double t;
@@ -523,6 +551,17 @@ __device__ __forceinline__ void apply_ureg(double2 (&amp)[kRegAmps], double u, d
         const int ra = ((k & ~lo) << 1) | (k & lo), rb = (((k + 1) & ~lo) << 1) | ((k + 1) & lo);
         const int ra1 = ra | (1 << J), rb1 = rb | (1 << J);
         rot_quad(amp[ra].x, amp[ra1].x, amp[ra].y, amp[ra1].y, amp[rb].x, amp[rb1].x, amp[rb].y, amp[rb1].y, u, s);
+    }
+}
+
+template <int J>
+__device__ __forceinline__ void apply_ureg2(double2 (&amp)[kRegAmps], double t, double y) {
+    constexpr int lo = (1 << J) - 1;
+#pragma unroll
+    for (int k = 0; k < kRegAmps / 2; k += 2) {
+        const int ra = ((k & ~lo) << 1) | (k & lo), rb = (((k + 1) & ~lo) << 1) | ((k + 1) & lo);
+        const int ra1 = ra | (1 << J), rb1 = rb | (1 << J);
+        rot2_quad(amp[ra].x, amp[ra1].x, amp[ra].y, amp[ra1].y, amp[rb].x, amp[rb1].x, amp[rb].y, amp[rb1].y, t, y);
     }
 }
 
@@ -638,6 +677,7 @@ struct Ctx {
     const double2* ph2;
     char* xbuf;           // LDS transposition buffer
     const unsigned short* smask;  // LDS: [sign table][thread] 16-bit sign masks
+    const unsigned char* smask8 = nullptr;  // ... the same as bytes (two runs side by side: LDS is short there; five bits are used)
     // LDS (sweep kernel, may be null): per diagonal stage the thread-only phase factor in two tables, one by the
     // low half of the thread bits and one by the high half; valid while no phase slot is patched
     const double2* ftab;
@@ -687,13 +727,13 @@ __device__ __forceinline__ void do_xpose(double2 (&amp)[kRegAmps], const Prog& p
             const int off = wt ^ ((r & 1) ? w0 : 0) ^ ((r & 2) ? w1 : 0) ^ ((r & 4) ? w2 : 0);
             *(double2*)(cx.xbuf + off) = amp[r + 8 * half];
         }
-        __syncthreads();
+        if (!(VQA_EXP & 64)) __syncthreads();
 #pragma unroll
         for (int r = 0; r < kRegAmps / 2; ++r) {
             const int off = rt ^ ((r & 1) ? r0 : 0) ^ ((r & 2) ? r1 : 0) ^ ((r & 4) ? r2 : 0);
             amp[r + 8 * half] = *(const double2*)(cx.xbuf + off);
         }
-        __syncthreads();
+        if (!(VQA_EXP & 64)) __syncthreads();
     }
 }
 
@@ -783,6 +823,9 @@ __device__ __forceinline__ void do_diag_masked(double2 (&amp)[kRegAmps], const P
 
 
 // One diagonal stage (descriptor did).
+// SCALES: phase slots may carry the scales of two-shear rotations (see compute_uentry): a slot P stands for
+// the factor P on |0> and conj(P) / |P|^2 on |1>; without, every slot has modulus one and the latter is conj(P).
+template <bool SCALES = false>
 __device__ __forceinline__ void do_diag(double2 (&amp)[kRegAmps], const Prog& pp, const Ctx& cx, int did, bool use_ftab) {
     // the whole descriptor in one go (field by field each scalar load is waited for where it is used)
     static_assert(sizeof(DDesc) == 48, "DDesc is fetched as three 16-byte scalar loads");
@@ -844,14 +887,22 @@ __device__ __forceinline__ void do_diag(double2 (&amp)[kRegAmps], const Prog& pp
         cplx F = { 1.0, 0.0 };
         for (int i = 0; i < cx.T; ++i) {
             const double2 p = p1[kRegBits + i];
-            F = cmul(F, csel_conj({ p.x, p.y }, (unsigned)(t >> i) & 1u));
+            const unsigned bit = (unsigned)(t >> i) & 1u;
+            cplx f = csel_conj({ p.x, p.y }, bit);
+            if (SCALES) {
+                const double sc = bit ? 1.0 / (p.x * p.x + p.y * p.y) : 1.0;
+                f = { f.x * sc, f.y * sc };
+            }
+            F = cmul(F, f);
         }
-        // effective phase of each register bit
+        // effective phase of each register bit (with SCALES: and one over its squared modulus)
         cplx pj[kRegBits];
+        double ij[kRegBits];
 #pragma unroll
         for (int j = 0; j < kRegBits; ++j) {
             const double2 p = p1[j];
             pj[j] = { p.x, p.y };
+            ij[j] = SCALES ? 1.0 / (p.x * p.x + p.y * p.y) : 1.0;
         }
         for (int k = 0; k < rt_count; ++k) {
             const int pa = pp.pairs[rt_begin + k].a, pb = pp.pairs[rt_begin + k].b;
@@ -862,15 +913,19 @@ __device__ __forceinline__ void do_diag(double2 (&amp)[kRegAmps], const Prog& pp
                 if (pa == j) pj[j] = cmul(pj[j], ze);
         }
         tb[0] = thread_pairs(cmul(cmul(F, cmul(pj[0], pj[1])), cmul(pj[2], pj[3])));
+        // the step of register bit j: (factor on |1>) / (factor on |0>) = (conj(p) / |p|^2)^2
+        auto step_raw = [&](int j) {
+            cplx cj = cconj(pj[j]);
+            if (SCALES) cj = { cj.x * ij[j], cj.y * ij[j] };
+            return cmul(cj, cj);
+        };
 #pragma unroll
         for (int j = 0; j < kRegBits - 1; ++j) {
-            const cplx cj = cconj(pj[j]);
-            const cplx w = step_of(cmul(cj, cj), j);
+            const cplx w = step_of(step_raw(j), j);
 #pragma unroll
             for (int r = 0; r < (1 << j); ++r) tb[r | (1 << j)] = cmul(tb[r], w);
         }
-        const cplx c3 = cconj(pj[kRegBits - 1]);
-        w3 = step_of(cmul(c3, c3), kRegBits - 1);
+        w3 = step_of(step_raw(kRegBits - 1), kRegBits - 1);
     }
 #pragma unroll
     for (int r = 0; r < kRegAmps / 2; ++r) {
@@ -907,7 +962,8 @@ struct NoHook {
     __device__ __forceinline__ void operator()(double2 (&)[kRegAmps], int) const {}
 };
 // hook(amp, d): called in front of diagonal stage d (grouped sweeps: checkpoints in LDS, late corrections)
-template <bool SCALED, bool MASKED = false, class Hook = NoHook>
+// TWO: register-bit entries may be of the two-shear form, phase slots may carry their scales
+template <bool SCALED, bool MASKED = false, class Hook = NoHook, bool TWO = false>
 __device__ __forceinline__ void run_phases(double2 (&amp)[kRegAmps], const Prog& pp, Ctx& cx, int p0,
                                            bool diag_only_first, bool ckpt, bool use_ftab = false, Hook hook = Hook()) {
     const VQA_CAS PhaseOp* ph = pp.phases;
@@ -921,7 +977,10 @@ __device__ __forceinline__ void run_phases(double2 (&amp)[kRegAmps], const Prog&
 #ifdef VQA_PROF
         const int flags = d0.x & first_mask & cx.flag_mask;
 #else
-        const int flags = d0.x & first_mask;
+        constexpr int exp_mask = ~(((VQA_EXP & 128) ? PH_XPOSE : 0) | ((VQA_EXP & 256) ? PH_UREG0 * 15 : 0) |
+                                   ((VQA_EXP & 512) ? PH_ULANE0 * 15 : 0) | ((VQA_EXP & 1024) ? PH_ULANE0 * 0x30 : 0) |
+                                   ((VQA_EXP & 2048) ? PH_DIAG : 0));
+        const int flags = d0.x & first_mask & (ckpt ? -1 : exp_mask);
 #endif
         first_mask = -1;
         if (flags & PH_END) break;
@@ -932,7 +991,15 @@ __device__ __forceinline__ void run_phases(double2 (&amp)[kRegAmps], const Prog&
         double2 cs = cx.mat[ent[0]], csn;
 #define VQA_REG_SLOT(J)                                           \
         csn = cx.mat[ent[J + 1]];                                 \
-        if (flags & (PH_UREG0 << J)) apply_ureg<J>(amp, cs.x, cs.y); \
+        if constexpr (!TWO) {                                     \
+            if (flags & (PH_UREG0 << J)) apply_ureg<J>(amp, cs.x, cs.y); \
+        } else {                                                  \
+            /* (two optional blocks, not an if / else: each updates the amplitudes in place) */ \
+            const int two = __builtin_amdgcn_readfirstlane(__double2hiint(cs.y)) < 0; \
+            const int run = flags & (PH_UREG0 << J);              \
+            if (run && !two) apply_ureg<J>(amp, cs.x, cs.y);      \
+            if (run && two) apply_ureg2<J>(amp, cs.x, cs.y);      \
+        }                                                         \
         cs = csn;
         VQA_REG_SLOT(0) VQA_REG_SLOT(1) VQA_REG_SLOT(2) VQA_REG_SLOT(3)
 #undef VQA_REG_SLOT
@@ -964,7 +1031,7 @@ __device__ __forceinline__ void run_phases(double2 (&amp)[kRegAmps], const Prog&
             if (ckpt) store_state(amp, cx.area, (unsigned)did * cx.image_bytes, cx.nthr, cx.tid());
             hook(amp, did);
             if constexpr (MASKED) do_diag_masked(amp, pp, cx, did);
-            else do_diag(amp, pp, cx, did, use_ftab);
+            else do_diag<TWO>(amp, pp, cx, did, use_ftab);
         }
         VQA_STAMP(13)
     }
@@ -1137,17 +1204,17 @@ __device__ __forceinline__ void measure_pair(double2 (&amp)[kRegAmps], unsigned 
     u32x4 pv[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-        if (!psi_lds) pv[r] = __builtin_amdgcn_raw_buffer_load_b128(cx.area, toff, psi_image + r * rstep, VQA_IMAGE_AUX);
+        if (!psi_lds && !(VQA_EXP & 2)) pv[r] = __builtin_amdgcn_raw_buffer_load_b128(cx.area, toff, psi_image + r * rstep, VQA_IMAGE_AUX);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int r = 0; r < kRegAmps; ++r) {
         if (psi_lds) break;
         const u32x4 cur = pv[r & 3];
-        const double2 ps = VQA_ABL(a, 10) ? make_double2(1.0, 0.5) : *(const double2*)&cur;
+        const double2 ps = (VQA_ABL(a, 10) || (VQA_EXP & 2)) ? make_double2(1.0, 0.5) : *(const double2*)&cur;
         const double2 ph = amp[r];
         pr[r] = ph.x * ph.x + ph.y * ph.y;
         amp[r] = make_double2(ps.x * ph.x + ps.y * ph.y, ps.x * ph.y - ps.y * ph.x);
-        if (r + 4 < kRegAmps)
+        if (r + 4 < kRegAmps && !(VQA_EXP & 2))
             pv[r & 3] = __builtin_amdgcn_raw_buffer_load_b128(cx.area, toff, psi_image + (r + 4) * rstep, VQA_IMAGE_AUX);
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -1436,7 +1503,7 @@ __device__ __forceinline__ void apply_correction(double2 (&amp)[kRegAmps], const
 // bag: the (A, G) of the sample's unshifted fused 2x2s where the caller keeps them (else A is worked out again).
 // LATE: 0 = patched tables; 1 = late resumption of the pair runs (sweep kernel); 2 = of every parameter that
 // allows it, the ones of the last U-stage included (grouped sweeps: the run named is the +shift one of the pair)
-template <int BLOCK, bool SCALED = true, int LATE = 0>
+template <int BLOCK, bool SCALED = true, int LATE = 0, bool TWO = false>
 __device__ __forceinline__ void make_run_record(const RegArgs& a, const Prog& pp, int r, const double* row, int NU, int N1,
                                                 RunRec* out, const double2* bag = nullptr) {
     const int i = pp.runs[r].param, variant = pp.runs[r].variant;
@@ -1454,10 +1521,12 @@ __device__ __forceinline__ void make_run_record(const RegArgs& a, const Prog& pp
         } else {
             double2 mv;
             cplx G, gp;
-            compute_uentry<SCALED>(pp, index, a.theta, row, -1, 0.0, -1, mv, A, G, gp);
+            compute_uentry<SCALED, TWO>(pp, index, a.theta, row, -1, 0.0, -1, mv, A, G, gp);
         }
+        // (A may carry the scale of a two-shear rotation: the frame is diag(A, conj(A) / |A|^2))
         const cplx A2 = cmul(A, A);
-        c01 = cmul(c01, cconj(A2));
+        const double i4 = TWO ? 1.0 / (A2.x * A2.x + A2.y * A2.y) : 1.0;
+        c01 = cmul(c01, cplx{ A2.x * i4, -A2.y * i4 });
         c10 = cmul(c10, A2);
         double sk, ck;
         sincos(0.5 * coef * a.spec.shift, &sk, &ck);
@@ -1491,11 +1560,15 @@ __device__ __forceinline__ void make_run_record(const RegArgs& a, const Prog& pp
         cplx A[2], G[2], gp[2];
 #pragma unroll 1
         for (int v = 0; v < 2; ++v)
-            compute_uentry<SCALED>(pp, index, a.theta, row, (v == 1 && variant != 0) ? i : -1, shift,
-                                 (v == 1 && variant == 0) ? i : -1, mv[v], A[v], G[v], gp[v]);
+            compute_uentry<SCALED, TWO>(pp, index, a.theta, row, (v == 1 && variant != 0) ? i : -1, shift,
+                                      (v == 1 && variant == 0) ? i : -1, mv[v], A[v], G[v], gp[v]);
         m = mv[1];
         fb = cmul(cconj(G[0]), G[1]);
-        fa = cmul(cconj(A[0]), A[1]);
+        fa = cmul(cconj(A[0]), A[1]);   // A[1] / A[0] (the moduli differ when a two-shear form carries its scale)
+        if (TWO) {
+            const double i0 = 1.0 / (A[0].x * A[0].x + A[0].y * A[0].y);
+            fa = { fa.x * i0, fa.y * i0 };
+        }
         rho = cmul(gp[1], cconj(gp[0]));
         id_m = index;
         if (pp.uent[index].d_before >= 0) id_b = NU + pp.uent[index].d_before;
@@ -1530,6 +1603,15 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : BLOCK == 512 ? 2 : BLOCK
     // one state per workgroup: the thread bits are the workgroup's size (a constant lets the loops over
     // them unroll, so that their table reads are issued together)
     constexpr int T = BLOCK == 64 ? 6 : BLOCK == 128 ? 7 : BLOCK == 256 ? 8 : BLOCK == 512 ? 9 : 10;
+    // two-shear register rotations (the 1024-thread workgroups keep the masked diagonal stages, which take unit slots)
+    // (measured at 12 qubits, depth 10: a fifth of the kernel's FP64 multiply-adds less, and 2 % MORE time -- the test of
+    // the form in front of every rotation, a readfirstlane and a scalar branch, costs each wave more of its own
+    // serial time than the multiply-adds it saves; off unless built with -DVQA_TWO_SHEAR)
+#ifdef VQA_TWO_SHEAR
+    constexpr bool TWO = BLOCK < 1024;
+#else
+    constexpr bool TWO = false;
+#endif
     const int n = pp.H->n;
     const int NU = pp.H->n_uent, N1 = pp.H->n_d1, N2 = pp.H->n_d2, ND = pp.H->n_ddesc;
     const int P = pp.H->n_params, NR = pp.H->n_runs;
@@ -1594,27 +1676,35 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : BLOCK == 512 ? 2 : BLOCK
         const double* row = a.input + (size_t)b * a.n_input;
         VQA_STAMP0
         __syncthreads();
-        prep_tables<true, true>(a, pp, tabs, j, 1, NU, N1, N2, tid, BLOCK);
+        prep_tables<true, true, TWO>(a, pp, tabs, j, 1, NU, N1, N2, tid, BLOCK);
         for (int r = tid; r < NR; r += BLOCK)
-            make_run_record<BLOCK, true, 1>(a, pp, r, row, NU, N1, a.recs + (size_t)blockIdx.x * NR + r);
+            make_run_record<BLOCK, true, 1, TWO>(a, pp, r, row, NU, N1, a.recs + (size_t)blockIdx.x * NR + r);
         __threadfence_block();
         // the thread-only factors of the diagonal stages, by halves of the thread bits (unpatched tables)
         __syncthreads();
-        for (int i = tid; i < (BLOCK == 1024 ? 0 : ND * (FE + kRegBits)); i += BLOCK) {
+        for (int i = tid; i < ((BLOCK == 1024 || !a.use_ftab) ? 0 : ND * (FE + kRegBits)); i += BLOCK) {
             const int d = i / (FE + kRegBits), e = i - d * (FE + kRegBits);
             const double2* p1 = cx.ph1 + pp.ddesc[d].ph1_base;
             cplx f = { 1.0, 0.0 };
+            // (a slot P stands for the factor P on |0> and conj(P) / |P|^2 on |1>: two-shear rotations leave their scales there)
             if (e >= FE) {
                 // the step of register bit e - FE
                 const double2 p = p1[e - FE];
-                const cplx cj = { p.x, -p.y };
+                const double inv = TWO ? 1.0 / (p.x * p.x + p.y * p.y) : 1.0;
+                const cplx cj = { p.x * inv, -p.y * inv };
                 f = cmul(cj, cj);
             } else {
                 const bool high = e >= (1 << TL);
                 const int bits = high ? e - (1 << TL) : e, b0 = high ? TL : 0, nb = high ? T - TL : TL;
                 for (int k = 0; k < nb; ++k) {
                     const double2 p = p1[kRegBits + b0 + k];
-                    f = cmul(f, csel_conj({ p.x, p.y }, (unsigned)(bits >> k) & 1u));
+                    const unsigned bit = (unsigned)(bits >> k) & 1u;
+                    cplx g = csel_conj({ p.x, p.y }, bit);
+                    if (TWO && bit) {
+                        const double inv = 1.0 / (p.x * p.x + p.y * p.y);
+                        g = { g.x * inv, g.y * inv };
+                    }
+                    f = cmul(f, g);
                 }
                 if (!high) {
                     // the register bits' own phases (all bits clear) ride in the low table
@@ -1673,6 +1763,10 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : BLOCK == 512 ? 2 : BLOCK
             double2 amp[kRegAmps];
             int pc0 = 0;
             if (rdiag >= 0) {
+                if ((VQA_EXP & 1) && r >= 0) {
+#pragma unroll
+                    for (int q = 0; q < kRegAmps; ++q) amp[q] = make_double2(0.015625 * (q + 1), 0.0078125);
+                } else
                 if (!VQA_ABL(a, 6)) load_state(amp, cx.area, (unsigned)rdiag * cx.image_bytes, BLOCK, tid);
                 pc0 = rpc;
             } else {
@@ -1683,16 +1777,16 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : BLOCK == 512 ? 2 : BLOCK
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             // late resumption: the checkpoint is the unshifted state behind the parameter's U-stage; the
             // run's state there differs by a 2x2 on the one qubit (the record is not replaced before the end of the run)
-            if (late) apply_correction(amp, pz, late, cx);
+            if (late && !(VQA_EXP & 16)) apply_correction(amp, pz, late, cx);
             VQA_STAMP(1)
             // the next run's record travels while this run computes
-            if (ri + 1 < NL && (tid & 63) < 8) nx = recs[(size_t)live[ri + 1] * 8 + (tid & 63)];
+            if (!(VQA_EXP & 32) && ri + 1 < NL && (tid & 63) < 8) nx = recs[(size_t)live[ri + 1] * 8 + (tid & 63)];
             // (a run that patches a phase slot works the thread-only factors out bit by bit)
-            if (!VQA_ABL(a, 8))
-                run_phases<true, BLOCK == 1024>(amp, pp, cx, pc0, rdiag >= 0, r < 0, !(VQA_EXP & 4) && id_b < 0 && id_a < 0);
+            if (!VQA_ABL(a, 8) && !((VQA_EXP & 4) && r >= 0))
+                run_phases<true, BLOCK == 1024, NoHook, TWO>(amp, pp, cx, pc0, rdiag >= 0, r < 0, a.use_ftab && id_b < 0 && id_a < 0);
             VQA_STAMP(2)
             if (r < 0) store_state(amp, cx.area, (unsigned)ND * cx.image_bytes, BLOCK, tid);
-            if (!VQA_ABL(a, 4)) {
+            if (!VQA_ABL(a, 4) && !((VQA_EXP & 8) && r >= 0)) {
                 if (mode == 1) {
                     measure_pair(amp, (unsigned)ND * cx.image_bytes, basev[79], pz, basev, a, pp, cx, red, parity,
                                  j * K + kout, valid);
@@ -1705,6 +1799,526 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : BLOCK == 512 ? 2 : BLOCK
             VQA_STAMP(3)
             // hand the fetched record over (read by everybody after the barrier on top)
             if (tid < 8 && ri + 1 < NL) pz[tid] = nx;
+        }
+    }
+}
+
+// ---- full parameter-shift sweeps, two runs of a sample side by side ----------------------------
+// The sweep kernel above keeps three workgroups on a CU (three waves on a SIMD), and a wave spends two thirds
+// of its time waiting -- for its workgroup's barriers, LDS round trips, descriptor fetches and state images --
+// not issuing arithmetic.  Here a workgroup runs TWO runs of its sample in lock-step, sixteen amplitudes of each
+// per thread (two workgroups on a CU, 256 registers per thread): every wait, barrier, scalar instruction,
+// descriptor and table read serves both, the diagonal stage's table is built once, and runs that resume from
+// the same checkpoint load it once and share the loads of the unshifted final state in the measurement.
+// Items of the work list (a.live: two numbers per item) are pairs of late-resumption runs of one diagonal
+// stage, or a single run with -1 beside it (patched tables, the runs left over at a stage's end); a single
+// run takes a copy of itself along as the second state, which writes nothing.
+
+// sums of NV values over the workgroup, every thread gets them (the layout of state_sum's buffer with up to
+// eight waves: the two kinds of calls may alternate on the same two halves of red)
+template <int NV>
+__device__ __forceinline__ void state_sum2(double (&v)[NV], const Ctx& cx, double* red, unsigned& parity) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = wave_sum(v[k]);
+    if (cx.T > 6) {
+        const int wave = cx.wave, nwave = cx.nthr >> 6;
+        double* buf = red + (parity & 1u) * 64;
+        parity = __builtin_amdgcn_readfirstlane(parity ^ 1u);
+        if (cx.lane() == 0) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) buf[k * 8 + wave] = v[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            v[k] = 0.0;
+            for (int w = 0; w < nwave; ++w) v[k] += buf[k * 8 + w];
+        }
+    }
+}
+
+// do_xpose for two states: state B goes through the second half-size buffer behind the first
+__device__ __forceinline__ void do_xpose2(double2 (&ampA)[kRegAmps], double2 (&ampB)[kRegAmps], const Prog& pp, Ctx& cx, int xid,
+                                          int half_bytes) {
+    const VQA_CAS XDesc* xd = pp.xdesc + xid;
+    if (xid != cx.xc_id) {
+        int wt = 0, rt = 0;
+        const int t = cx.t();
+        for (int i = 0; i < cx.T; ++i) {
+            const int m = -((t >> i) & 1);
+            wt ^= m & xd->wconst[kRegBits + i];
+            rt ^= m & xd->rconst[kRegBits + i];
+        }
+        cx.xc_id = xid;
+        cx.xc_wt = wt;
+        cx.xc_rt = rt;
+    }
+    const int wt = cx.xc_wt, rt = cx.xc_rt;
+    const int w0 = xd->wconst[0], w1 = xd->wconst[1], w2 = xd->wconst[2];
+    const int r0 = xd->rconst[0], r1 = xd->rconst[1], r2 = xd->rconst[2];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int r = 0; r < kRegAmps / 2; ++r) {
+            const int off = wt ^ ((r & 1) ? w0 : 0) ^ ((r & 2) ? w1 : 0) ^ ((r & 4) ? w2 : 0);
+            *(double2*)(cx.xbuf + off) = ampA[r + 8 * half];
+            *(double2*)(cx.xbuf + half_bytes + off) = ampB[r + 8 * half];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < kRegAmps / 2; ++r) {
+            const int off = rt ^ ((r & 1) ? r0 : 0) ^ ((r & 2) ? r1 : 0) ^ ((r & 4) ? r2 : 0);
+            ampA[r + 8 * half] = *(const double2*)(cx.xbuf + off);
+            ampB[r + 8 * half] = *(const double2*)(cx.xbuf + half_bytes + off);
+        }
+        __syncthreads();
+    }
+}
+
+// do_diag for two states that share the stage's tables: the thread's phase table is built once
+__device__ __forceinline__ void do_diag2(double2 (&ampA)[kRegAmps], double2 (&ampB)[kRegAmps], const Prog& pp, const Ctx& cx,
+                                         int did, bool use_ftab) {
+    const VQA_CAS i32x4* ddv = (const VQA_CAS i32x4*)(pp.ddesc + did);
+    const i32x4 dd0 = ddv[0], dd1 = ddv[1];
+    struct { int ph1_base, tt_begin, tt_count, rt_begin, rt_count, rr_begin, rr_count, sign_id; } ddl =
+        { dd0.x, dd0.y, dd0.z, dd0.w, dd1.x, dd1.y, dd1.z, dd1.w };
+    const auto* dd = &ddl;
+    const double2* p1 = cx.ph1 + dd->ph1_base;
+    const int t = cx.t();
+    const int sign_id = dd->sign_id;
+    unsigned sm = 0, rr = 0;
+    if (sign_id >= 0) {
+        sm = cx.smask8[sign_id * cx.nthr + cx.tid()];
+        rr = pp.signs[sign_id].rr_par;
+    }
+    const int tt_begin = dd->tt_begin, tt_count = dd->tt_count;
+    const int rt_begin = dd->rt_begin, rt_count = dd->rt_count;
+    cplx tb[kRegAmps / 2], w3;
+    auto step_of = [&](cplx w, int j) {
+        const unsigned cr = (sm >> (1 + j)) & 1u;
+        return cplx{ flip_if(w.x, cr), flip_if(w.y, cr) };
+    };
+    auto thread_pairs = [&](cplx T0) {
+        T0 = { flip_if(T0.x, sm & 1u), flip_if(T0.y, sm & 1u) };
+        for (int k = 0; k < tt_count; ++k) {
+            const int pa = pp.pairs[tt_begin + k].a, pb = pp.pairs[tt_begin + k].b;
+            const double2 z = cx.ph2[pp.pairs[tt_begin + k].ph2];
+            T0 = cmul(T0, csel_conj({ z.x, z.y }, (unsigned)((t >> pa) ^ (t >> pb)) & 1u));
+        }
+        return T0;
+    };
+    if (use_ftab && rt_count == 0) {
+        const int TL = cx.T >> 1, FE = (1 << TL) + (1 << (cx.T - TL));
+        const double2* ft = cx.ftab + (size_t)did * (FE + kRegBits);
+        const double2 fa = ft[t & ((1 << TL) - 1)], fb = ft[(1 << TL) + (t >> TL)];
+        tb[0] = thread_pairs(cmul({ fa.x, fa.y }, { fb.x, fb.y }));
+#pragma unroll
+        for (int j = 0; j < kRegBits - 1; ++j) {
+            const double2 wj = ft[FE + j];
+            const cplx w = step_of({ wj.x, wj.y }, j);
+#pragma unroll
+            for (int r = 0; r < (1 << j); ++r) tb[r | (1 << j)] = cmul(tb[r], w);
+        }
+        const double2 wl = ft[FE + kRegBits - 1];
+        w3 = step_of({ wl.x, wl.y }, kRegBits - 1);
+    } else {
+        cplx F = { 1.0, 0.0 };
+        for (int i = 0; i < cx.T; ++i) {
+            const double2 p = p1[kRegBits + i];
+            F = cmul(F, csel_conj({ p.x, p.y }, (unsigned)(t >> i) & 1u));
+        }
+        cplx pj[kRegBits];
+#pragma unroll
+        for (int j = 0; j < kRegBits; ++j) {
+            const double2 p = p1[j];
+            pj[j] = { p.x, p.y };
+        }
+        for (int k = 0; k < rt_count; ++k) {
+            const int pa = pp.pairs[rt_begin + k].a, pb = pp.pairs[rt_begin + k].b;
+            const double2 z = cx.ph2[pp.pairs[rt_begin + k].ph2];
+            const cplx ze = csel_conj({ z.x, z.y }, (unsigned)(t >> pb) & 1u);
+#pragma unroll
+            for (int j = 0; j < kRegBits; ++j)
+                if (pa == j) pj[j] = cmul(pj[j], ze);
+        }
+        tb[0] = thread_pairs(cmul(cmul(F, cmul(pj[0], pj[1])), cmul(pj[2], pj[3])));
+#pragma unroll
+        for (int j = 0; j < kRegBits - 1; ++j) {
+            const cplx cj = cconj(pj[j]);
+            const cplx w = step_of(cmul(cj, cj), j);
+#pragma unroll
+            for (int r = 0; r < (1 << j); ++r) tb[r | (1 << j)] = cmul(tb[r], w);
+        }
+        const cplx c3 = cconj(pj[kRegBits - 1]);
+        w3 = step_of(cmul(c3, c3), kRegBits - 1);
+    }
+#pragma unroll
+    for (int r = 0; r < kRegAmps / 2; ++r) {
+        const cplx hi = cmul(tb[r], w3);
+        cmul_inplace(ampA[r].x, ampA[r].y, tb[r].x, tb[r].y);
+        cmul_inplace(ampB[r].x, ampB[r].y, tb[r].x, tb[r].y);
+        cmul_inplace(ampA[r + 8].x, ampA[r + 8].y, hi.x, hi.y);
+        cmul_inplace(ampB[r + 8].x, ampB[r + 8].y, hi.x, hi.y);
+    }
+    if (rr) {
+#pragma unroll
+        for (int r = 0; r < kRegAmps; ++r) {
+            const double sg = ((rr >> r) & 1u) ? -1.0 : 1.0;
+            asm("v_mul_f64 %0, %0, %2\n\tv_mul_f64 %1, %1, %2" : "+v"(ampA[r].x), "+v"(ampA[r].y) : "s"(sg));
+            asm("v_mul_f64 %0, %0, %2\n\tv_mul_f64 %1, %1, %2" : "+v"(ampB[r].x), "+v"(ampB[r].y) : "s"(sg));
+        }
+    }
+    const int rr_begin = dd->rr_begin, rr_count = dd->rr_count;
+    for (int k = 0; k < rr_count; ++k) {
+        const int pa = pp.pairs[rr_begin + k].a, pb = pp.pairs[rr_begin + k].b;
+        const double2 z = cx.ph2[pp.pairs[rr_begin + k].ph2];
+#pragma unroll
+        for (int r = 0; r < kRegAmps; ++r) {
+            const cplx ze = csel_conj({ z.x, z.y }, (unsigned)((r >> pa) ^ (r >> pb)) & 1u);
+            cmul_inplace(ampA[r].x, ampA[r].y, ze.x, ze.y);
+            cmul_inplace(ampB[r].x, ampB[r].y, ze.x, ze.y);
+        }
+    }
+}
+
+// run_phases for two states (the scaled lane forms; the table form of the diagonal stages); ckpt: state A's
+// images in front of the diagonal stages are stored
+__device__ __forceinline__ void run_phases2(double2 (&ampA)[kRegAmps], double2 (&ampB)[kRegAmps], const Prog& pp, Ctx& cx, int p0,
+                                            bool diag_only_first, bool ckpt, bool use_ftab, int half_bytes) {
+    const VQA_CAS PhaseOp* ph = pp.phases;
+    int first_mask = diag_only_first ? (PH_DIAG | PH_END) : -1;
+    for (int p = p0;; ++p) {
+        const VQA_CAS i32x4* dsc = (const VQA_CAS i32x4*)(ph + p);
+        const i32x4 d0 = dsc[0], d1 = dsc[1], d2 = dsc[2], d3 = dsc[3];
+        const int ent[10] = { d0.w, d1.x, d1.y, d1.z, d1.w, d2.x, d2.y, d2.z, d2.w, d3.x };
+        const int flags = d0.x & first_mask;
+        first_mask = -1;
+        if (flags & PH_END) break;
+        if (flags & PH_XPOSE) do_xpose2(ampA, ampB, pp, cx, d0.y, half_bytes);
+        double2 cs = cx.mat[ent[0]], csn;
+#define VQA_REG_SLOT2(J)                                          \
+        csn = cx.mat[ent[J + 1]];                                 \
+        if (flags & (PH_UREG0 << J)) {                            \
+            apply_ureg<J>(ampA, cs.x, cs.y);                      \
+            apply_ureg<J>(ampB, cs.x, cs.y);                      \
+        }                                                         \
+        cs = csn;
+        VQA_REG_SLOT2(0) VQA_REG_SLOT2(1) VQA_REG_SLOT2(2) VQA_REG_SLOT2(3)
+#undef VQA_REG_SLOT2
+#define VQA_LANE_SLOT2(LB)                                                 \
+        csn = cx.mat[ent[LB + 5 < 10 ? LB + 5 : 9]];                       \
+        {                                                                  \
+            const int form_b = __builtin_amdgcn_readfirstlane(__double2hiint(cs.y)); \
+            const int run = flags & (PH_ULANE0 << LB);                     \
+            if (run && form_b == 0) {                                      \
+                apply_ulane<LB, 1>(ampA, cs.x, cs.y, cx.lane());           \
+                apply_ulane<LB, 1>(ampB, cs.x, cs.y, cx.lane());           \
+            }                                                              \
+            if (run && form_b != 0) {                                      \
+                apply_ulane<LB, 2>(ampA, cs.x, cs.y, cx.lane());           \
+                apply_ulane<LB, 2>(ampB, cs.x, cs.y, cx.lane());           \
+            }                                                              \
+        }                                                                  \
+        cs = csn;
+        VQA_LANE_SLOT2(0) VQA_LANE_SLOT2(1) VQA_LANE_SLOT2(2) VQA_LANE_SLOT2(3)
+#undef VQA_LANE_SLOT2
+        if (flags & (PH_ULANE0 * 0x30)) {
+            const double2 c5 = cx.mat[ent[9]];
+            const bool h4 = (flags & (PH_ULANE0 << 4)) != 0, h5 = (flags & (PH_ULANE0 << 5)) != 0;
+            const double c4v = h4 ? cs.x : 1.0, s4v = h4 ? cs.y : 0.0, c5v = h5 ? c5.x : 1.0, s5v = h5 ? c5.y : 0.0;
+            apply_ulane45(ampA, c4v, s4v, c5v, s5v, cx.lane());
+            apply_ulane45(ampB, c4v, s4v, c5v, s5v, cx.lane());
+        }
+        if (flags & PH_DIAG) {
+            const int did = d0.z;
+            if (ckpt) store_state(ampA, cx.area, (unsigned)did * cx.image_bytes, cx.nthr, cx.tid());
+            do_diag2(ampA, ampB, pp, cx, did, use_ftab);
+        }
+    }
+}
+
+// measure_pair for two pair runs of one sample: the unshifted final state is loaded once
+__device__ __forceinline__ void measure_pair2(double2 (&ampA)[kRegAmps], double2 (&ampB)[kRegAmps], unsigned psi_image,
+                                              double psi_norm, const double2* recA, const double2* recB, const double* basev,
+                                              const RegArgs& a, const Prog& pp, const Ctx& cx, double* red, unsigned& parity,
+                                              int64_t e1A, int64_t e1B, bool valid) {
+    const double nanv = __longlong_as_double(0x7ff8000000000000LL);
+    unsigned kt, krb[kRegBits];
+    const int t = cx.t();
+    measure_masks(pp, cx.T, t, kt, krb);
+    const int nq = a.obs.n_obs + (a.n_marg_bits > 0 ? (1 << a.n_marg_bits) : 0);
+    const unsigned toff = cx.tid() * (unsigned)sizeof(double2), rstep = cx.nthr * (unsigned)sizeof(double2);
+    double prA[kRegAmps], prB[kRegAmps];
+    // amp <- conj(psi) phi, pr <- |phi|^2 for both states; the loads of psi run eight ahead
+    u32x4 pv[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) pv[r] = __builtin_amdgcn_raw_buffer_load_b128(cx.area, toff, psi_image + r * rstep, VQA_IMAGE_AUX);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < kRegAmps; ++r) {
+        const u32x4 cur = pv[r & 7];
+        const double2 ps = *(const double2*)&cur;
+        const double2 pa = ampA[r], pb = ampB[r];
+        prA[r] = pa.x * pa.x + pa.y * pa.y;
+        prB[r] = pb.x * pb.x + pb.y * pb.y;
+        ampA[r] = make_double2(ps.x * pa.x + ps.y * pa.y, ps.x * pa.y - ps.y * pa.x);
+        ampB[r] = make_double2(ps.x * pb.x + ps.y * pb.y, ps.x * pb.y - ps.y * pb.x);
+        if (r + 8 < kRegAmps)
+            pv[r & 7] = __builtin_amdgcn_raw_buffer_load_b128(cx.area, toff, psi_image + (r + 8) * rstep, VQA_IMAGE_AUX);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    double inA = 1.0, icA = 1.0, inB = 1.0, icB = 1.0;
+    for (int q = 0; q < nq; ++q) {
+        // per state: sum o |phi|^2, Re / Im sum o conj(psi) phi; with the first quantity the norms
+        double v[8] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
+        if (q == 0) {
+#pragma unroll
+            for (int r = 0; r < kRegAmps; ++r) { v[6] += prA[r]; v[7] += prB[r]; }
+        }
+        if (q < a.obs.n_obs) {
+            for (int tm = a.obs.off[q]; tm < a.obs.off[q + 1]; ++tm) {
+                const unsigned z = (unsigned)a.obs.z[tm];
+                const unsigned tpar = __popc(kt & z);
+                double p[6] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+                for (int r = 0; r < kRegAmps; ++r) {
+                    unsigned rp = tpar;
+#pragma unroll
+                    for (int j = 0; j < kRegBits; ++j)
+                        if (r & (1 << j)) rp += __popc(krb[j] & z);
+                    const double sg = __hiloint2double((int)(0x3FF00000u | ((rp & 1u) << 31)), 0);
+                    p[0] = fma(sg, prA[r], p[0]);
+                    p[1] = fma(sg, ampA[r].x, p[1]);
+                    p[2] = fma(sg, ampA[r].y, p[2]);
+                    p[3] = fma(sg, prB[r], p[3]);
+                    p[4] = fma(sg, ampB[r].x, p[4]);
+                    p[5] = fma(sg, ampB[r].y, p[5]);
+                }
+                const double cf = a.obs.coef[tm];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) v[k] += cf * p[k];
+            }
+        } else {
+            const unsigned m = (unsigned)(q - a.obs.n_obs), M1 = (1u << a.n_marg_bits) - 1;
+#pragma unroll
+            for (int r = 0; r < kRegAmps; ++r) {
+                unsigned k = kt;
+#pragma unroll
+                for (int j = 0; j < kRegBits; ++j)
+                    if (r & (1 << j)) k |= krb[j];
+                const double w = (k & M1) == m ? 1.0 : 0.0;
+                v[0] = fma(w, prA[r], v[0]);
+                v[1] = fma(w, ampA[r].x, v[1]);
+                v[2] = fma(w, ampA[r].y, v[2]);
+                v[3] = fma(w, prB[r], v[3]);
+                v[4] = fma(w, ampB[r].x, v[4]);
+                v[5] = fma(w, ampB[r].y, v[5]);
+            }
+        }
+        if (q == 0) {
+            state_sum2<8>(v, cx, red, parity);
+            inA = 1.0 / v[6]; icA = rsqrt(v[6] * psi_norm);
+            inB = 1.0 / v[7]; icB = rsqrt(v[7] * psi_norm);
+        } else {
+            double w[6] = { v[0], v[1], v[2], v[3], v[4], v[5] };
+            state_sum2<6>(w, cx, red, parity);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) v[k] = w[k];
+        }
+        // threads 0 and 1 write one run's two values each
+        if (t < 2) {
+            const bool is_obs = q < a.obs.n_obs;
+            const int64_t e1 = t == 0 ? e1A : e1B;
+            const size_t o1 = is_obs ? (size_t)e1 * a.obs.n_obs + q : ((size_t)e1 << a.n_marg_bits) + (q - a.obs.n_obs);
+            const size_t step = is_obs ? (size_t)a.obs.n_obs : ((size_t)1 << a.n_marg_bits);
+            double* out = is_obs ? a.out_expect : a.out_marginal;
+            const double2* rec = t == 0 ? recA : recB;
+            const double2 rho = rec[3], cs = rec[4];
+            const double s0 = t == 0 ? v[0] : v[3], s1 = t == 0 ? v[1] : v[4], s2 = t == 0 ? v[2] : v[5];
+            const double inv_norm = t == 0 ? inA : inB, inv_cross = t == 0 ? icA : icB;
+            const double im = (rho.x * s2 + rho.y * s1) * inv_cross;
+            const double mid = cs.x * cs.x * basev[q] + cs.y * cs.y * s0 * inv_norm;
+            const double dev = 2.0 * cs.x * cs.y * im;
+            out[o1] = valid ? mid - dev : nanv;
+            out[o1 + step] = valid ? mid + dev : nanv;
+        }
+    }
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK, VQA_PSR2_WAVES) void k_reg_psr2(RegArgs a) {
+    extern __shared__ double2 smem[];
+    const Prog pp = load_prog(a.prog);
+    constexpr int T = BLOCK == 64 ? 6 : BLOCK == 128 ? 7 : BLOCK == 256 ? 8 : 9;
+    const int n = pp.H->n;
+    const int NU = pp.H->n_uent, N1 = pp.H->n_d1, N2 = pp.H->n_d2, ND = pp.H->n_ddesc;
+    const int P = pp.H->n_params, NR = pp.H->n_runs;
+    const int tid = threadIdx.x;
+    const int t = tid;
+    const int half_bytes = pp.H->has_xpose ? (8 << n) : 0;   // one half-size transposition buffer per state
+
+    // (the transposition buffers first: their addresses are then constants of the kernel)
+    double2* xbuf = smem;
+    double2* tabs = (double2*)((char*)smem + 2 * (size_t)half_bytes);
+    double* red = (double*)(tabs + (size_t)(NU + N1 + N2));
+    double2* pz = (double2*)(red + 128);                  // the records of the current item's two runs (2 x 8 entries)
+    double2* sav = pz + 16;                               // what the current patch replaced (3 entries, thread 0's)
+    double* basev = (double*)(sav + 4);                   // the unshifted values (79 entries), squared norm of psi
+    unsigned char* smask8 = (unsigned char*)(basev + 80);
+    constexpr int TL = T >> 1, FE = (1 << TL) + (1 << (T - TL));
+    double2* ftab = (double2*)((char*)smask8 + (((size_t)pp.H->n_sign * BLOCK + 15) & ~(size_t)15));
+
+    Ctx cx;
+    cx.mat = tabs; cx.ph1 = tabs + NU; cx.ph2 = tabs + NU + N1;
+    cx.xbuf = (char*)xbuf;
+    cx.smask = nullptr;
+    cx.smask8 = smask8;
+    cx.ftab = ftab;
+    cx.T = T; cx.nthr = BLOCK;
+    cx.wave = __builtin_amdgcn_readfirstlane(tid >> 6); cx.tmask = (1 << T) - 1;
+    cx.xc_id = -1; cx.xc_wt = 0; cx.xc_rt = 0;
+#ifdef VQA_PROF
+    cx.flag_mask = -1;
+#endif
+    // per-thread sign bits of every sign table: bit 0 the thread's own parity, bit 1 + j the flip that register bit j brings
+    for (int sg = 0; sg < pp.H->n_sign; ++sg) {
+        const int wi = t >> 5, bi = t & 31;
+        unsigned m = (pp.signs[sg].tt_par[wi] >> bi) & 1u;
+#pragma unroll
+        for (int jj = 0; jj < kRegBits; ++jj) m |= ((pp.signs[sg].cross[jj][wi] >> bi) & 1u) << (1 + jj);
+        smask8[sg * BLOCK + tid] = (unsigned char)m;
+    }
+
+    cx.image_bytes = 16u << n;
+    cx.area = __builtin_amdgcn_make_buffer_rsrc((void*)(a.ckpt + (size_t)blockIdx.x * ((size_t)(ND + 1) << n)), 0,
+                                                (ND + 1) * cx.image_bytes, 0x00020000);
+    const double2* recs = (const double2*)(a.recs + (size_t)blockIdx.x * NR);
+    const int K = 2 * P + 1;
+    unsigned parity = 0;
+
+    __shared__ unsigned s_next2;
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) s_next2 = atomicAdd(a.next, 1u);
+        __syncthreads();
+        const int64_t item = s_next2;
+        const int64_t j = item / a.split;
+        const int slice = (int)(item - j * a.split);
+        if (j >= a.E) break;
+        int b = a.spec.sel ? a.spec.sel[j] : (int)j;
+        const bool valid = a.spec.B == 0 || (unsigned)b < (unsigned)a.spec.B;
+        if (!valid) b = 0;
+        const double* row = a.input + (size_t)b * a.n_input;
+        __syncthreads();
+        prep_tables<true, true>(a, pp, tabs, j, 1, NU, N1, N2, tid, BLOCK);
+        for (int r = tid; r < NR; r += BLOCK)
+            make_run_record<BLOCK, true, 1>(a, pp, r, row, NU, N1, a.recs + (size_t)blockIdx.x * NR + r);
+        __threadfence_block();
+        __syncthreads();
+        for (int i = tid; i < ND * (FE + kRegBits); i += BLOCK) {
+            const int d = i / (FE + kRegBits), e = i - d * (FE + kRegBits);
+            const double2* p1 = cx.ph1 + pp.ddesc[d].ph1_base;
+            cplx f = { 1.0, 0.0 };
+            if (e >= FE) {
+                const double2 p = p1[e - FE];
+                const cplx cj = { p.x, -p.y };
+                f = cmul(cj, cj);
+            } else {
+                const bool high = e >= (1 << TL);
+                const int bits = high ? e - (1 << TL) : e, b0 = high ? TL : 0, nb = high ? T - TL : TL;
+                for (int k = 0; k < nb; ++k) {
+                    const double2 p = p1[kRegBits + b0 + k];
+                    f = cmul(f, csel_conj({ p.x, p.y }, (unsigned)(bits >> k) & 1u));
+                }
+                if (!high) {
+                    for (int jj = 0; jj < kRegBits; ++jj) {
+                        const double2 p = p1[jj];
+                        f = cmul(f, { p.x, p.y });
+                    }
+                }
+            }
+            ftab[i] = make_double2(f.x, f.y);
+        }
+
+        // item -1 is the unshifted circuit; thread 0 keeps what the current patch replaced
+        int old_m = -1, old_b = -1, old_a = -1;
+        double2 nx = make_double2(0, 0);
+        const int lo = (int)((int64_t)a.n_live * slice / a.split), NI = (int)((int64_t)a.n_live * (slice + 1) / a.split) - lo;
+        const int32_t* live = a.live + 2 * (size_t)lo;
+        for (int it = -1; it <= NI; ++it) {
+            const int rA = it < 0 ? -1 : it < NI ? live[2 * it] : NR;
+            const int rB = (it >= 0 && it < NI) ? live[2 * it + 1] : -1;
+            __syncthreads();   // the previous item is over (tables free); its successor's records are in pz
+            int id_m = -1, id_b = -1, id_a = -1, mode = 0, kout = 0, rdiag = -1, rpc = 0, late = 0, koutB = 0, lateB = 0;
+            if (rA >= 0 && rA < NR) {
+                const int4 ids = *(const int4*)&pz[5], o = *(const int4*)&pz[6];
+                id_m = __builtin_amdgcn_readfirstlane(ids.x);
+                id_b = __builtin_amdgcn_readfirstlane(ids.y);
+                id_a = __builtin_amdgcn_readfirstlane(ids.z);
+                late = __builtin_amdgcn_readfirstlane(ids.w);
+                mode = __builtin_amdgcn_readfirstlane(o.x);
+                kout = __builtin_amdgcn_readfirstlane(o.y);
+                rdiag = __builtin_amdgcn_readfirstlane(o.z);
+                rpc = __builtin_amdgcn_readfirstlane(o.w);
+            }
+            if (rB >= 0) {
+                const int4 ids = *(const int4*)&pz[8 + 5], o = *(const int4*)&pz[8 + 6];
+                lateB = __builtin_amdgcn_readfirstlane(ids.w);
+                koutB = __builtin_amdgcn_readfirstlane(o.y);
+            }
+            if (tid == 0) {
+                if (old_a >= 0) tabs[old_a] = sav[2];
+                if (old_b >= 0) tabs[old_b] = sav[1];
+                if (old_m >= 0) tabs[old_m] = sav[0];
+                if (id_m >= 0) { sav[0] = tabs[id_m]; tabs[id_m] = pz[0]; }
+                if (id_b >= 0) {
+                    const double2 o = tabs[id_b], f = pz[1];
+                    sav[1] = o;
+                    const cplx q = cmul({ o.x, o.y }, { f.x, f.y });
+                    tabs[id_b] = make_double2(q.x, q.y);
+                }
+                if (id_a >= 0) {
+                    const double2 o = tabs[id_a], f = pz[2];
+                    sav[2] = o;
+                    const cplx q = cmul({ o.x, o.y }, { f.x, f.y });
+                    tabs[id_a] = make_double2(q.x, q.y);
+                }
+            }
+            old_m = id_m; old_b = id_b; old_a = id_a;
+            if (rA == NR) break;
+            double2 ampA[kRegAmps], ampB[kRegAmps];
+            int pc0 = 0;
+            if (rdiag >= 0) {
+                load_state(ampA, cx.area, (unsigned)rdiag * cx.image_bytes, BLOCK, tid);
+                pc0 = rpc;
+            } else {
+#pragma unroll
+                for (int q = 0; q < kRegAmps; ++q) ampA[q] = make_double2(0.0, 0.0);
+                if (t == 0) ampA[0].x = 1.0;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            // the second state starts from the same image (a single run: as a copy that writes nothing)
+#pragma unroll
+            for (int q = 0; q < kRegAmps; ++q) ampB[q] = ampA[q];
+            if (late) apply_correction(ampA, pz, late, cx);
+            if (rB >= 0) apply_correction(ampB, pz + 8, lateB, cx);
+            // the next item's records travel while this one computes
+            if (it + 1 < NI && (tid & 63) < 16) {
+                const int rn = live[2 * (it + 1) + ((tid & 63) >> 3)];
+                if (rn >= 0) nx = recs[(size_t)rn * 8 + (tid & 7)];
+            }
+            run_phases2(ampA, ampB, pp, cx, pc0, rdiag >= 0, rA < 0, id_b < 0 && id_a < 0, half_bytes);
+            if (rA < 0) store_state(ampA, cx.area, (unsigned)ND * cx.image_bytes, BLOCK, tid);
+            if (rB >= 0) {
+                measure_pair2(ampA, ampB, (unsigned)ND * cx.image_bytes, basev[79], pz, pz + 8, basev, a, pp, cx, red, parity,
+                              j * K + kout, j * K + koutB, valid);
+            } else if (mode == 1) {
+                measure_pair(ampA, (unsigned)ND * cx.image_bytes, basev[79], pz, basev, a, pp, cx, red, parity, j * K + kout, valid);
+            } else {
+                const double nrm = measure(ampA, a, pp, cx, red, parity, j * K + kout, true, valid, rA < 0 ? basev : nullptr);
+                if (rA < 0 && tid == 0) basev[79] = nrm;
+            }
+            if (tid < 16 && it + 1 < NI) pz[tid] = nx;
         }
     }
 }
@@ -2124,6 +2738,7 @@ static RegArgs make_args(const EvalCall& call, const void* d_prog) {
     a.n_live = 0;
     a.need_psi = 0;
     a.split = 1;
+    a.use_ftab = 1;
 #ifdef VQA_PROF
     const char* abl = getenv("VQA_ABLATE");
     a.ablate = abl ? atoi(abl) : 0;
@@ -2196,17 +2811,68 @@ int reg_engine_sweep(const EvalCall& call, const void* d_prog, const RegProgram&
         for (int32_t i : cone.dead_list)
             if (call.param_mask[i]) m_dead.push_back(i);
     }
-    const std::vector<int32_t>& live_runs = call.param_mask ? m_live : cone.reg_live_runs;
+    const std::vector<int32_t>& runs_1 = call.param_mask ? m_live : cone.reg_live_runs;
     const std::vector<int32_t>& dead_list = call.param_mask ? m_dead : cone.dead_list;
     const int n_dead = (int)dead_list.size();
-    const size_t n_live = live_runs.size();
+    // Two runs side by side (k_reg_psr2): the list becomes items of two runs, pairs of late-resumption runs
+    // that load the same checkpoint, or a run on its own with -1 beside it.  Taken when a state spans at most
+    // eight waves, the two half-size transposition buffers fit LDS and at least a third of the runs find a partner.
+    auto pair_up = [&](const std::vector<int32_t>& runs, std::vector<int32_t>& items) {
+        int n_pairs = 0;
+        auto late_stage = [&](int32_t r) {
+            const ParamInfo& pi = P.params[P.runs[r].param];
+            return (P.runs[r].variant == 0 && pi.late_mask != 0) ? pi.late_diag : -1;
+        };
+        for (size_t k = 0; k < runs.size(); ++k) {
+            const int ls = late_stage(runs[k]);
+            if (ls >= 0 && k + 1 < runs.size() && late_stage(runs[k + 1]) == ls) {
+                items.push_back(runs[k]); items.push_back(runs[k + 1]);
+                ++k; ++n_pairs;
+            } else {
+                items.push_back(runs[k]); items.push_back(-1);
+            }
+        }
+        return n_pairs;
+    };
+    const size_t half_x = P.hdr.has_xpose ? ((size_t)8 << P.hdr.n) : 0;
+    // + state B's buffer, the second record, the patch slots; the sign masks as bytes
+    const size_t mask16 = ((size_t)P.hdr.n_sign * P.hdr.block * 2 + 15) & ~(size_t)15, mask8 = ((size_t)P.hdr.n_sign * P.hdr.block + 15) & ~(size_t)15;
+    const size_t lds_psr2 = P.lds_bytes_psr + half_x + 8 * 16 + 4 * 16 - mask16 + mask8;
+    // (workgroups a CU holds either way: the side-by-side form must keep more runs in flight)
+    const int by_regs = P.hdr.block <= 128 ? VQA_SMALL_WAVES * 4 / (P.hdr.block / 64) : 8;
+    const int per_cu_1 = std::max<int>(1, std::min<int>(std::min(by_regs, VQA_WAVES * 4 / std::max(P.hdr.block / 64, 1)),
+                                                        (int)((160 * 1024) / std::max<size_t>(P.lds_bytes_psr, 1))));
+    const int per_cu_2 = std::min<int>(8 / std::max(P.hdr.block / 64, 1), (int)((160 * 1024 - 64) / std::max<size_t>(lds_psr2, 1)));
+    // (measured, IBM-HEA with <Z0>, gradients/s side by side against one run per workgroup: 10 qubits 608 k / 598 k,
+    // 11 qubits 206 k / 226 k, 12 qubits 79.0 k / 78.3 k with half the state-image traffic, 13 qubits 47.8 k / 42.7 k:
+    // taken from 12 qubits on, where a state spans four waves or more)
+    bool two_runs = P.hdr.block >= 256 && P.hdr.block <= 512 && 2 * per_cu_2 > per_cu_1 && !getenv("VQA_NO_PSR2");
+    if (getenv("VQA_PSR2")) two_runs = P.hdr.block <= 512 && per_cu_2 >= 1;   // (experiments: wherever it runs)
+    std::vector<int32_t> m_items;
+    if (two_runs) {
+        if (call.param_mask) {
+            two_runs = 3 * pair_up(m_live, m_items) >= (int)m_live.size() / 2 && !m_items.empty();
+        } else {
+            std::lock_guard<std::mutex> lk(call.c->mu);
+            if (!cone.reg_pairs_built) {
+                cone.reg_pairs = pair_up(cone.reg_live_runs, cone.reg_live_items);
+                cone.reg_pairs_built = true;
+            }
+            two_runs = 3 * cone.reg_pairs >= (int)cone.reg_live_runs.size() / 2 && !cone.reg_live_items.empty();
+        }
+    }
+    const std::vector<int32_t>& live_runs = !two_runs ? runs_1 : call.param_mask ? m_items : cone.reg_live_items;
+    const size_t n_live = live_runs.size();   // entries of the uploaded list (two per item with two_runs)
     // (each list starts on a 16-byte boundary: the allocation-free upload stores 16 bytes at a time)
     const size_t live_part = (n_live * sizeof(int32_t) + 15) & ~(size_t)15;
     const size_t live_bytes = (live_part + (size_t)n_dead * sizeof(int32_t) + 255) & ~(size_t)255;
     // resident workgroups per CU: what LDS allows, and the register budget of the launch bounds for
     // the one- and two-wave workgroups of 10 and 11 qubits (VQA_WAVES waves per SIMD)
-    const int by_regs = P.hdr.block <= 128 ? VQA_SMALL_WAVES * 4 / (P.hdr.block / 64) : 8;
-    const int per_cu = std::max<int>(1, std::min<int>(by_regs, (int)((160 * 1024) / std::max<size_t>(P.lds_bytes_psr, 1))));
+    // (timing experiments: VQA_NO_FTAB=1 leaves the diagonal stages' thread-factor tables out of LDS)
+    a.use_ftab = getenv("VQA_NO_FTAB") ? 0 : 1;
+    const size_t lds_psr = two_runs ? lds_psr2 : P.lds_bytes_psr - (a.use_ftab ? 0 : P.lds_bytes_ftab);
+    // (two runs side by side: 256 registers per thread, two waves per SIMD)
+    const int per_cu = two_runs ? per_cu_2 : std::max<int>(1, std::min<int>(by_regs, (int)((160 * 1024) / std::max<size_t>(lds_psr, 1))));
     // every workgroup of the launch owns an area of state images and run records; a call with a
     // fixed region of working memory launches as many workgroups as the region holds areas for
     // (workgroups draw samples from a counter, so any grid size completes the sweep)
@@ -2228,6 +2894,9 @@ int reg_engine_sweep(const EvalCall& call, const void* d_prog, const RegProgram&
     const int grid = (int)std::min<int64_t>((int64_t)n_samples * split, slots);
     const size_t ck_bytes = (size_t)grid * (P.hdr.n_ddesc + 1) * ((size_t)16 << P.hdr.n);
     const size_t rec_bytes = (size_t)grid * std::max(P.hdr.n_runs, 1) * sizeof(RunRec);
+    if (getenv("VQA_PLAN_DEBUG"))
+        fprintf(stderr, "[vqa] register sweep: %s, %zu list entries, LDS %zu bytes, %d workgroups per CU, grid %d, split %d\n",
+                two_runs ? "two runs side by side" : "one run per workgroup", n_live, lds_psr, per_cu, grid, split);
     void* ws = nullptr;
     rc = call_workspace(call, 256 + live_bytes + ck_bytes + rec_bytes, &ws);
     if (rc) return rc;
@@ -2237,24 +2906,36 @@ int reg_engine_sweep(const EvalCall& call, const void* d_prog, const RegProgram&
     a.ckpt = (double2*)((char*)ws + 256 + live_bytes);
     a.recs = (RunRec*)((char*)ws + 256 + live_bytes + ck_bytes);
     a.live = d_live;
-    a.n_live = (int)n_live;
-    a.split = (int)std::max<size_t>(1, std::min<size_t>((size_t)split, n_live));
+    a.n_live = (int)(two_runs ? n_live / 2 : n_live);
+    a.split = (int)std::max<size_t>(1, std::min<size_t>((size_t)split, (size_t)a.n_live));
     VQA_HIP(hipMemsetAsync(a.next, 0, 256, call.stream));
     // (the lists live as long as the circuit: the asynchronous copies may read them after this returns)
     if (n_live && (rc = call_upload(call, d_live, live_runs.data(), n_live * sizeof(int32_t)))) return rc;
     if (n_dead && (rc = call_upload(call, d_dead, dead_list.data(), (size_t)n_dead * sizeof(int32_t)))) return rc;
-    const void* fn = P.hdr.block == 64 ? (const void*)k_reg_psr<64>
+    const void* fn = two_runs ? (P.hdr.block == 64 ? (const void*)k_reg_psr2<64>
+                               : P.hdr.block == 128 ? (const void*)k_reg_psr2<128>
+                               : P.hdr.block == 256 ? (const void*)k_reg_psr2<256>
+                                                    : (const void*)k_reg_psr2<512>)
+                   : P.hdr.block == 64 ? (const void*)k_reg_psr<64>
                    : P.hdr.block == 128 ? (const void*)k_reg_psr<128>
                    : P.hdr.block == 256 ? (const void*)k_reg_psr<256>
                    : P.hdr.block == 512 ? (const void*)k_reg_psr<512>
                                         : (const void*)k_reg_psr<1024>;
-    VQA_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.lds_bytes_psr));
+    VQA_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_psr));
+    if (two_runs) {
+        switch (P.hdr.block) {
+        case 64: hipLaunchKernelGGL(k_reg_psr2<64>, dim3(grid), dim3(64), lds_psr, call.stream, a); break;
+        case 128: hipLaunchKernelGGL(k_reg_psr2<128>, dim3(grid), dim3(128), lds_psr, call.stream, a); break;
+        case 256: hipLaunchKernelGGL(k_reg_psr2<256>, dim3(grid), dim3(256), lds_psr, call.stream, a); break;
+        default: hipLaunchKernelGGL(k_reg_psr2<512>, dim3(grid), dim3(512), lds_psr, call.stream, a); break;
+        }
+    } else
     switch (P.hdr.block) {
-    case 64: hipLaunchKernelGGL(k_reg_psr<64>, dim3(grid), dim3(64), P.lds_bytes_psr, call.stream, a); break;
-    case 128: hipLaunchKernelGGL(k_reg_psr<128>, dim3(grid), dim3(128), P.lds_bytes_psr, call.stream, a); break;
-    case 256: hipLaunchKernelGGL(k_reg_psr<256>, dim3(grid), dim3(256), P.lds_bytes_psr, call.stream, a); break;
-    case 512: hipLaunchKernelGGL(k_reg_psr<512>, dim3(grid), dim3(512), P.lds_bytes_psr, call.stream, a); break;
-    default: hipLaunchKernelGGL(k_reg_psr<1024>, dim3(grid), dim3(1024), P.lds_bytes_psr, call.stream, a); break;
+    case 64: hipLaunchKernelGGL(k_reg_psr<64>, dim3(grid), dim3(64), lds_psr, call.stream, a); break;
+    case 128: hipLaunchKernelGGL(k_reg_psr<128>, dim3(grid), dim3(128), lds_psr, call.stream, a); break;
+    case 256: hipLaunchKernelGGL(k_reg_psr<256>, dim3(grid), dim3(256), lds_psr, call.stream, a); break;
+    case 512: hipLaunchKernelGGL(k_reg_psr<512>, dim3(grid), dim3(512), lds_psr, call.stream, a); break;
+    default: hipLaunchKernelGGL(k_reg_psr<1024>, dim3(grid), dim3(1024), lds_psr, call.stream, a); break;
     }
     VQA_HIP(hipGetLastError());
     if (n_dead) {

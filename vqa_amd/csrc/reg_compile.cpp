@@ -665,6 +665,19 @@ bool reg_compile(int n, int n_theta, const std::vector<vqa_op>& gate_list, RegPr
     }
     H.n_runs = (int)P.runs.size();
 
+    if (getenv("VQA_PLAN_DEBUG") && atoi(getenv("VQA_PLAN_DEBUG")) >= 2) {
+        // the phases: x = transposition, rJ / lJ = rotation on register / lane bit J, D = diagonal stage
+        for (size_t k = 0; k < P.phases.size(); ++k) {
+            const PhaseOp& ph = P.phases[k];
+            fprintf(stderr, "[vqa]   phase %2zu:", k);
+            if (ph.flags & PH_XPOSE) fprintf(stderr, " x%d", ph.xdesc);
+            for (int j = 0; j < 4; ++j) if (ph.flags & (PH_UREG0 << j)) fprintf(stderr, " r%d", j);
+            for (int j = 0; j < 6; ++j) if (ph.flags & (PH_ULANE0 << j)) fprintf(stderr, " l%d", j);
+            if (ph.flags & PH_DIAG) fprintf(stderr, " D%d", ph.ddesc);
+            if (ph.flags & PH_END) fprintf(stderr, " end");
+            fprintf(stderr, "\n");
+        }
+    }
     H.n_uent = (int)P.uent.size();
     H.n_d1 = (int)P.d1.size();
     H.n_d2 = (int)P.d2.size();
@@ -691,9 +704,12 @@ bool reg_compile(int n, int n_theta, const std::vector<vqa_op>& gate_list, RegPr
     P.lds_bytes = (size_t)H.S * tab1 + xbuf + fixed + (size_t)H.n_uent * 48;
     // + run record, unshifted values, the diagonal stages' thread-factor tables (two per stage, by halves of the thread bits)
     // (the 1024-thread workgroups keep the diagonal stages' earlier form and have no such tables)
-    P.lds_bytes_psr = tab1 + xbuf + fixed + 16 * 16 + 80 * sizeof(double) +
-                      (H.block >= 1024 ? 0 : (size_t)H.n_ddesc * ((1 << (T >> 1)) + (1 << (T - (T >> 1))) + kRegBits) * 16 + 16);
+    P.lds_bytes_ftab = H.block >= 1024 ? 0 : (size_t)H.n_ddesc * ((1 << (T >> 1)) + (1 << (T - (T >> 1))) + kRegBits) * 16 + 16;
+    P.lds_bytes_psr = tab1 + xbuf + fixed + 16 * 16 + 80 * sizeof(double) + P.lds_bytes_ftab;
     // (64 bytes of margin for the kernels' few statically allocated words)
+    if (getenv("VQA_PLAN_DEBUG"))
+        fprintf(stderr, "[vqa] register program: LDS %zu bytes (explicit lists), %zu (sweeps): tables %zu, transposition buffer %zu, sign masks %zu\n",
+                P.lds_bytes, P.lds_bytes_psr, tab1, xbuf, (size_t)H.n_sign * H.block * 2);
     if (std::max(P.lds_bytes, P.lds_bytes_psr) + 64 > 160 * 1024) { *why = "per-evaluation tables do not fit LDS"; return false; }
 
     // ---- device blob ----

@@ -211,6 +211,7 @@ struct RegProgram {
     std::vector<char> blob;  // header + arrays, as uploaded
     size_t lds_bytes = 0;      // explicit-list kernel (S states per workgroup)
     size_t lds_bytes_psr = 0;  // parameter-shift kernel (one state per workgroup)
+    size_t lds_bytes_ftab = 0; // ... of which the diagonal stages' thread-factor tables (the last part of the area)
     int n_dense_gates = 0, n_xpose = 0, n_diag = 0;
 };
 

@@ -134,6 +134,9 @@ struct ConeInfo {
     std::vector<int32_t> dead_list;          // the dead parameters, ascending
     bool reg_built = false;
     std::vector<int32_t> reg_live_runs;      // engine 2: runs of the live parameters, in run order
+    bool reg_pairs_built = false;
+    int reg_pairs = 0;                       // ... how many pairs the list below holds
+    std::vector<int32_t> reg_live_items;     // ... the same runs as items of two (the second -1: a run on its own)
     bool group_built = false;
     std::vector<int32_t> group_live_k;       // engine 2, small circuits: runs of the live parameters, pair runs first
     bool group_late_built = false;
