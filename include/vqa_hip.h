@@ -277,6 +277,11 @@ int vqa_sample_counts(int device, const double* probs, int n_outcomes,
 int vqa_sample_counts_dev(int device, void* stream, const double* d_probs, int n_outcomes,
                           const int64_t* d_shots, int64_t E, uint64_t seed, uint64_t stream_id,
                           int64_t* d_counts);
+/* The same for one shard of a list of rows that several GPUs share: row e of the call draws from the
+ * counter of row e + row_offset, so a row's counts do not depend on how the list was split. */
+int vqa_sample_counts_shard_dev(int device, void* stream, const double* d_probs, int n_outcomes,
+                                const int64_t* d_shots, int64_t E, uint64_t seed, uint64_t stream_id,
+                                int64_t* d_counts, int64_t row_offset);
 
 /*
  * Estimator epilogue of the regressor's gradient oracles, on the device.  From the matrix of exact
@@ -307,6 +312,20 @@ int vqa_mse_stats_dev(int device, void* stream, const double* d_expect, const do
                       const double* d_weight, double n_shots0, int mode, uint64_t seed,
                       int want_variances, double n0, int second_order, double* d_workspace,
                       double* d_out_sums, double* d_out_m0, double* d_out_grad_data);
+/*
+ * The same for ONE SHARD of a mini-batch that several GPUs share (one process per GPU, contiguous
+ * blocks of samples): the B rows given are rows row_offset .. row_offset + B of the whole batch, and
+ * the random streams are named by the row's number in the whole batch, so the estimates a sample
+ * gets do not depend on how many ranks share the work.  The ranks add their out_sums (one
+ * all-reduce of (P+1) * 8 doubles) and finish as one process would.  The sample loop this shards:
+ * vqa/QNN/myQNNs_base.py:1114-1124 under 1370-1394 / 1469-1586.
+ */
+int vqa_mse_stats_shard_dev(int device, void* stream, const double* d_expect, const double* d_estimates,
+                            int64_t B, int P, const double* d_y, double w, const double* d_shots,
+                            const double* d_weight, double n_shots0, int mode, uint64_t seed,
+                            int want_variances, double n0, int second_order, double* d_workspace,
+                            double* d_out_sums, double* d_out_m0, double* d_out_grad_data,
+                            int64_t row_offset);
 
 /*
  * Gradient and variance estimates of the oracles with independent random shot allocation
@@ -341,6 +360,24 @@ int vqa_irandom_stats_dev(int device, void* stream, const double* d_expect, int 
 int vqa_class_grad_dev(int device, void* stream, const int64_t* d_counts, const int64_t* d_shots,
                        int64_t n_samples, int n_params, const int32_t* d_label, const double* d_onehot,
                        double* d_grad);
+
+/*
+ * The classifier's gradient oracles with variance estimates, from drawn class counts: per circuit
+ * parameter i, out_sums[4 i + 0] = sum over the samples of the per-sample gradient term, [1] = sum of
+ * the conditional-variance estimate, [2] = sum of the form the reference takes when the batch mean of
+ * [1] comes out negative ([3] unused).  kind 0: MSE on the true class alone (partial_MSE), 1: MSE over
+ * the three classes -- MSE_iEval, vqa/QNN/myQNNs_classifier.py:888-999 with
+ * _estimate_MSEgrad_mean_condVar, 861-886 (without want_variances: MSE_grad_eval, 1055-1156) --
+ * 2: cross entropy from the success counts -- CE_grad_eval / CE_iEval, 1172-1269 with
+ * _estimate_CEgrad_mean_condVar, 1158-1169 (the L2 term lambda * theta_i is the caller's).  Counts and
+ * shots as for vqa_class_grad_dev; labels[n_samples] are the class indices 0..2.  Sums, not means:
+ * the ranks of a batch split over several GPUs add them and divide by the whole batch size.
+ * d_out_grad_data: NULL or [n_params, n_samples], the per-sample gradient terms ('grad_data_list').
+ * Deterministic; queued on `stream`, not waited for.
+ */
+int vqa_class_stats_dev(int device, void* stream, const int64_t* d_counts, const int64_t* d_shots,
+                        int64_t n_samples, int n_params, const int32_t* d_label, int kind,
+                        int want_variances, double* d_out_sums, double* d_out_grad_data);
 
 /*
  * Final state of ONE instance, interleaved (re, im) doubles, 2 * 2^n values,

@@ -21,7 +21,7 @@ EXPORTS = (
     "vqa_observable_create", "vqa_observable_destroy",
     "vqa_eval_batch", "vqa_eval_batch_dev", "vqa_psr_full", "vqa_psr_full_dev",
     "vqa_statevector", "vqa_sample_counts", "vqa_sample_counts_dev", "vqa_dead_parameters", "vqa_psr_params_dev",
-    "vqa_psr_full_noalloc_dev", "vqa_mse_stats_workspace", "vqa_mse_stats_dev", "vqa_irandom_stats_dev", "vqa_class_grad_dev",
+    "vqa_psr_full_noalloc_dev", "vqa_mse_stats_workspace", "vqa_mse_stats_dev", "vqa_mse_stats_shard_dev", "vqa_irandom_stats_dev", "vqa_class_grad_dev", "vqa_class_stats_dev", "vqa_sample_counts_shard_dev",
 )
 
 
@@ -69,7 +69,9 @@ def lib():
     L.vqa_mse_stats_workspace.argtypes = [C.c_int64, C.c_int]
     L.vqa_mse_stats_dev.argtypes = [C.c_int, vp, dp, dp, C.c_int64, C.c_int, dp, C.c_double, dp, dp, C.c_double,
                                     C.c_int, C.c_uint64, C.c_int, C.c_double, C.c_int, dp, dp, dp, dp]
+    L.vqa_mse_stats_shard_dev.argtypes = L.vqa_mse_stats_dev.argtypes + [C.c_int64]
     L.vqa_class_grad_dev.argtypes = [C.c_int, vp, ip, ip, C.c_int64, C.c_int, ip, dp, dp]
+    L.vqa_class_stats_dev.argtypes = [C.c_int, vp, ip, ip, C.c_int64, C.c_int, ip, C.c_int, C.c_int, dp, dp]
     L.vqa_irandom_stats_dev.argtypes = [C.c_int, vp, dp, C.c_int, ip, dp, ip, ip, dp, C.c_int, C.c_int, C.c_int,
                                         C.c_double, C.c_double, C.c_uint64, dp]
     L.vqa_statevector.argtypes = [vp, C.c_int, dp, dp, C.c_int, C.c_double, dp]
@@ -78,6 +80,7 @@ def lib():
     L.vqa_dead_parameters.argtypes = [vp, vp, C.c_int, C.c_int, vp]
     L.vqa_sample_counts.argtypes = [C.c_int, dp, C.c_int, ip, C.c_int64, C.c_uint64, C.c_uint64, ip]
     L.vqa_sample_counts_dev.argtypes = [C.c_int, vp, dp, C.c_int, ip, C.c_int64, C.c_uint64, C.c_uint64, ip]
+    L.vqa_sample_counts_shard_dev.argtypes = L.vqa_sample_counts_dev.argtypes + [C.c_int64]
     for name in EXPORTS:
         fn = getattr(L, name)
         if name not in ("vqa_last_error", "vqa_mse_stats_workspace"):

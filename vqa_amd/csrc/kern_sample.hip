@@ -7,8 +7,8 @@
 // marginal exactly; this kernel draws the counts from it, one row (circuit instance) per
 // thread, as a chain of binomials: k_0 ~ Bin(n, p_0), k_1 ~ Bin(n - k_0, p_1 / (1 - p_0)), ...
 //
-// Random numbers: Philox-4x32-10 keyed by the caller's seed, counter = (row, draw number,
-// stream), so a row's counts depend only on (seed, stream, row, its probabilities and
+// Random numbers: Philox-4x32-10 keyed by the caller's seed, counter = (row + the caller's row
+// offset, draw number, stream), so a row's counts depend only on (seed, stream, row, its probabilities and
 // shots), not on the launch shape.  Binomials: sequential inversion while n * min(p, 1-p)
 // < 10, else Hoermann's transformed rejection with squeeze (BTRS, 1993); both exact.
 #include "philox.h"
@@ -21,11 +21,11 @@ namespace {
 constexpr int kT = 256;
 
 __global__ __launch_bounds__(kT) void k_sample_counts(const double* probs, int M, const int64_t* shots, int64_t E,
-                                                      uint64_t seed, uint64_t stream_id, int64_t* counts) {
+                                                      uint64_t seed, uint64_t stream_id, int64_t* counts, int64_t row0) {
     const int64_t e = (int64_t)blockIdx.x * kT + threadIdx.x;
     if (e >= E) return;
     Philox rng;
-    rng.init(seed, stream_id, (uint64_t)e);
+    rng.init(seed, stream_id, (uint64_t)(e + row0));
     int64_t left = shots[e] > 0 ? shots[e] : 0;
     double rest = 1.0;
     const double* p = probs + e * M;
@@ -69,10 +69,10 @@ int fill_dead_rows(hipStream_t stream, double* d_out, int64_t n_samples, int K, 
 }
 
 int sample_counts_launch(hipStream_t stream, const double* d_probs, int M, const int64_t* d_shots, int64_t E,
-                         uint64_t seed, uint64_t stream_id, int64_t* d_counts) {
+                         uint64_t seed, uint64_t stream_id, int64_t* d_counts, int64_t row_offset) {
     if (E <= 0) return VQA_OK;
     hipLaunchKernelGGL(k_sample_counts, dim3((unsigned)((E + kT - 1) / kT)), dim3(kT), 0, stream, d_probs, M, d_shots, E,
-                       seed, stream_id, d_counts);
+                       seed, stream_id, d_counts, row_offset);
     VQA_HIP(hipGetLastError());
     return VQA_OK;
 }

@@ -12,7 +12,7 @@
 //   mode 2  finite shots estimate = (n - 2 k) / n, k ~ Binomial(n, (1 - E) / 2)   (715-738)
 //   mode 3  given        the caller supplies the estimates (tests of the algebra)
 // Shots of instance (b, i): n = floor(shots[i] * weight[b]) (1367, 1383); the unshifted
-// evaluation uses n_shots0.  Random numbers: Philox streams named by (seed, b * K + column), so
+// evaluation uses n_shots0.  Random numbers: Philox streams named by (seed, (row0 + b) * K + column), so
 // results do not depend on the launch shape.  Unbiased powers: 843-847.
 //
 // Layout of the work: a workgroup takes a tile of samples; its threads are gradient components
@@ -37,6 +37,7 @@ struct StatsArgs {
     const double* shots;    // [P + 1] (scale parameter last); unused in mode 0
     const double* weight;   // [B] or null (all ones)
     int64_t B;
+    int64_t row0;           // number of the first row in the whole mini-batch (a shard of it): names the random streams
     int P;
     double w, n_shots0, n0;
     int mode, want_var, second_order;
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(kT) void k_mse_stats(StatsArgs a) {
         const double y = a.y[b], wt = a.weight ? a.weight[b] : 1.0;
         const double n = floor(a.n_shots0 * wt);
         const double e = a.E[b * K];
-        const double EX = a.mode == 3 ? a.est[b * K] : estimate1(a, e, n, (uint64_t)(b * K));
+        const double EX = a.mode == 3 ? a.est[b * K] : estimate1(a, e, n, (uint64_t)((b + a.row0) * K));
         double EX_2, EX_3, EX_4, var_0;
         if (a.mode == 0) {
             EX_2 = EX * EX; EX_3 = EX_2 * EX; EX_4 = EX_2 * EX_2;
@@ -158,14 +159,14 @@ __global__ __launch_bounds__(kT) void k_mse_stats(StatsArgs a) {
                 Mm = a.est[b * K + 2 + 2 * i];
             } else if (a.mode == 1) {
                 Philox rng;
-                rng.init(a.seed, 0, (uint64_t)(b * K + 1 + 2 * i));
+                rng.init(a.seed, 0, (uint64_t)((b + a.row0) * K + 1 + 2 * i));
                 double z0, z1;
                 rng.normal2(z0, z1);
                 Mp = e.x + z0 * sqrt(fmax(1.0 - e.x * e.x, 0.0) / n);
                 Mm = e.y + z1 * sqrt(fmax(1.0 - e.y * e.y, 0.0) / n);
             } else {
                 Philox rng;
-                rng.init(a.seed, 0, (uint64_t)(b * K + 1 + 2 * i));
+                rng.init(a.seed, 0, (uint64_t)((b + a.row0) * K + 1 + 2 * i));
                 const int64_t kp = binomial(rng, (int64_t)n, fmin(fmax(0.5 * (1.0 - e.x), 0.0), 1.0));
                 const int64_t km = binomial(rng, (int64_t)n, fmin(fmax(0.5 * (1.0 - e.y), 0.0), 1.0));
                 Mp = (n - 2.0 * (double)kp) / n;
@@ -354,7 +355,94 @@ __global__ __launch_bounds__(kT) void k_class_grad(const int64_t* __restrict__ c
     if (tid == 0) grad[i] = red[0] / (double)B;
 }
 
+// ---- classifier: gradient terms and conditional-variance estimates from drawn class counts ---------
+// vqa/QNN/myQNNs_classifier.py: MSE_iEval (888-999) with _estimate_MSEgrad_mean_condVar (861-886),
+// CE_grad_eval / CE_iEval (1172-1269) with _estimate_CEgrad_mean_condVar (1158-1169).  From the class
+// counts of the unshifted (k = 0) and shifted (k = 1 + 2 i, 2 + 2 i) circuits of every sample, a count c of
+// n shots gives p = c / n, the unbiased p2 = n / (n - 1) p^2 - p / (n - 1) and the sample variance
+// varp = c / (n - 1) - c^2 / (n (n - 1)) (623-627, 661-665).  Per component i the kernel sums over the samples
+//   [0] the per-sample gradient term, [1] the conditional-variance estimate, [2] the form the reference
+//   falls back to when the batch mean of [1] comes out negative:
+//   kind 0, partial MSE (success = the label's class): gd = (p0 - 1)(p+ - p-);
+//       [1] (p02 - 2 p0 + 1) vardp + varp0 (p+2 + p-2 - 2 p+ p-),  [2] (p0 - 1)^2 vardp + varp0 (p+ - p-)^2
+//   kind 1, full MSE, summed over the three classes with y the one-hot label: gd = sum (p0 - y)(p+ - p-);
+//       [1] sum (p02 + (1 - 2 p0) y) vardp + varp0 (p+2 + p-2 - 2 p+ p-),  [2] sum (p0 - y)^2 vardp + varp0 (p+ - p-)^2
+//   kind 2, cross entropy from success counts: gd = -(c+ - c-) / (2 (c0 + 1)) (n0 + 1) / (n + 1);
+//       with t = (n0 + 1) / (c0 + 1): [1] (t^2 (varp+ + varp-) + t^2 (t - 1)(p+2 + p-2 - 2 p+ p-)) / 4,
+//       [2] the same with (p+ - p-)^2
+// (vardp = varp+ + varp-).  Sums, not means: a batch that is split over several GPUs adds them.  One workgroup
+// per component, a thread takes every kT-th sample, fixed-order tree sum.
+struct Moments { double p, p2, varp; };
+__device__ __forceinline__ Moments count_moments(double c, double n) {
+    Moments m;
+    m.p = c / n;
+    m.varp = c / (n - 1.0) - c * c / (n * (n - 1.0));
+    m.p2 = (n / (n - 1.0)) * m.p * m.p - m.p / (n - 1.0);
+    return m;
+}
+
+__global__ __launch_bounds__(kT) void k_class_stats(const int64_t* __restrict__ counts, const int64_t* __restrict__ shots,
+                                                    int64_t B, int P, const int32_t* __restrict__ label, int kind,
+                                                    int want_var, double* __restrict__ out, double* __restrict__ gd_out) {
+    __shared__ double red[3][kT];
+    const int i = blockIdx.x, tid = threadIdx.x, K = 2 * P + 1;
+    double acc[3] = { 0.0, 0.0, 0.0 };
+    for (int64_t b = tid; b < B; b += kT) {
+        const int64_t r0 = b * K, rp = r0 + 1 + 2 * i, rm = rp + 1;
+        const double n0 = (double)shots[r0], n = (double)shots[rp];
+        const int y = label[b];
+        double gd = 0.0, main_v = 0.0, alt_v = 0.0;
+        if (kind == 2) {
+            const double c0 = (double)counts[3 * r0 + y], cp = (double)counts[3 * rp + y], cm = (double)counts[3 * rm + y];
+            gd = -0.5 * (cp - cm) / (c0 + 1.0) * ((n0 + 1.0) / (n + 1.0));
+            if (want_var) {
+                const Moments mp = count_moments(cp, n), mm = count_moments(cm, n);
+                const double t = (n0 + 1.0) / (c0 + 1.0), term1 = t * t * (mp.varp + mm.varp), vt = t * t * (t - 1.0);
+                const double d = mp.p - mm.p;
+                main_v = 0.25 * (term1 + vt * (mp.p2 + mm.p2 - 2.0 * mp.p * mm.p));
+                alt_v = 0.25 * (term1 + vt * d * d);
+            }
+        } else {
+            const int c_lo = kind == 0 ? y : 0, c_hi = kind == 0 ? y + 1 : 3;
+            for (int c = c_lo; c < c_hi; ++c) {
+                const Moments m0 = count_moments((double)counts[3 * r0 + c], n0);
+                const Moments mp = count_moments((double)counts[3 * rp + c], n), mm = count_moments((double)counts[3 * rm + c], n);
+                const double yc = (kind == 0 || c == y) ? 1.0 : 0.0;
+                const double d = mp.p - mm.p;
+                gd += (m0.p - yc) * d;
+                if (want_var) {
+                    const double vardp = mp.varp + mm.varp;
+                    // (partial MSE: y = 1, so p02 + (1 - 2 p0) y = p02 - 2 p0 + 1)
+                    main_v += (m0.p2 + (1.0 - 2.0 * m0.p) * yc) * vardp + m0.varp * (mp.p2 + mm.p2 - 2.0 * mp.p * mm.p);
+                    alt_v += (m0.p - yc) * (m0.p - yc) * vardp + m0.varp * d * d;
+                }
+            }
+        }
+        acc[0] += gd; acc[1] += main_v; acc[2] += alt_v;
+        if (gd_out) gd_out[(size_t)i * B + b] = gd;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) red[k][tid] = acc[k];
+    __syncthreads();
+    for (int h = kT / 2; h > 0; h >>= 1) {
+        if (tid < h) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) red[k][tid] += red[k][tid + h];
+        }
+        __syncthreads();
+    }
+    if (tid < 4) out[4 * i + tid] = tid < 3 ? red[tid][0] : 0.0;
+}
+
 }  // namespace
+
+int class_stats_launch(hipStream_t stream, const int64_t* d_counts, const int64_t* d_shots, int64_t B, int P,
+                       const int32_t* d_label, int kind, int want_var, double* d_out, double* d_gd) {
+    if (P <= 0) return VQA_OK;
+    hipLaunchKernelGGL(k_class_stats, dim3(P), dim3(kT), 0, stream, d_counts, d_shots, B, P, d_label, kind, want_var, d_out, d_gd);
+    VQA_HIP(hipGetLastError());
+    return VQA_OK;
+}
 
 int class_grad_launch(hipStream_t stream, const int64_t* d_counts, const int64_t* d_shots, int64_t B, int P,
                       const int32_t* d_label, const double* d_y1hot, double* d_grad) {
@@ -372,11 +460,11 @@ size_t mse_stats_workspace_bytes(int64_t B, int P) {
 int mse_stats_launch(hipStream_t stream, const double* d_E, const double* d_est, int64_t B, int P, const double* d_y,
                      double w, const double* d_shots, const double* d_weight, double n_shots0, int mode, uint64_t seed,
                      int want_var, double n0, int second_order, double* d_workspace, double* d_out, double* d_m0,
-                     double* d_gd) {
+                     double* d_gd, int64_t row_offset) {
     if (B <= 0) return VQA_OK;
     StatsArgs a;
     a.E = d_E; a.est = d_est; a.y = d_y; a.shots = d_shots; a.weight = d_weight;
-    a.B = B; a.P = P; a.w = w; a.n_shots0 = n_shots0; a.n0 = n0;
+    a.B = B; a.row0 = row_offset; a.P = P; a.w = w; a.n_shots0 = n_shots0; a.n0 = n0;
     a.mode = mode; a.want_var = want_var; a.second_order = second_order; a.seed = seed;
     a.partial = d_workspace; a.m0 = d_m0; a.gd = d_gd;
     const int64_t tiles = (B + kTile - 1) / kTile;

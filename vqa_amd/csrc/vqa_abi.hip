@@ -875,6 +875,36 @@ int vqa_sample_counts_dev(int device, void* stream, const double* d_probs, int n
     return sample_counts_launch((hipStream_t)stream, d_probs, n_outcomes, d_shots, E, seed, stream_id, d_counts);
 }
 
+int vqa_sample_counts_shard_dev(int device, void* stream, const double* d_probs, int n_outcomes,
+                                const int64_t* d_shots, int64_t E, uint64_t seed, uint64_t stream_id,
+                                int64_t* d_counts, int64_t row_offset) {
+    if (n_outcomes < 1 || n_outcomes > 1024) VQA_FAIL(VQA_EINVAL, "n_outcomes must be in [1, 1024] (got %d)", n_outcomes);
+    if (E < 0 || row_offset < 0) VQA_FAIL(VQA_EINVAL, "E and row_offset must be >= 0");
+    if (E == 0) return VQA_OK;
+    if (!d_probs || !d_shots || !d_counts) VQA_FAIL(VQA_EINVAL, "probs, shots and counts must not be NULL");
+    DeviceState* ds;
+    int rc = device_state(device, &ds);
+    if (rc) return rc;
+    VQA_HIP(hipSetDevice(device));
+    return sample_counts_launch((hipStream_t)stream, d_probs, n_outcomes, d_shots, E, seed, stream_id, d_counts, row_offset);
+}
+
+int vqa_class_stats_dev(int device, void* stream, const int64_t* d_counts, const int64_t* d_shots, int64_t n_samples,
+                        int n_params, const int32_t* d_label, int kind, int want_variances, double* d_out_sums,
+                        double* d_out_grad_data) {
+    if (n_samples < 0 || n_params < 0) VQA_FAIL(VQA_EINVAL, "n_samples and n_params must be >= 0");
+    if (kind < 0 || kind > 2) VQA_FAIL(VQA_EINVAL, "kind must be 0 (partial MSE), 1 (full MSE) or 2 (cross entropy)");
+    if (n_params == 0) return VQA_OK;
+    if (!d_out_sums) VQA_FAIL(VQA_EINVAL, "out_sums is NULL");
+    if (n_samples > 0 && (!d_counts || !d_shots || !d_label)) VQA_FAIL(VQA_EINVAL, "counts, shots and labels must not be NULL");
+    int count = 0;
+    VQA_HIP(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) VQA_FAIL(VQA_ENODEVICE, "device %d out of range (%d visible)", device, count);
+    VQA_HIP(hipSetDevice(device));
+    return class_stats_launch((hipStream_t)stream, d_counts, d_shots, n_samples, n_params, d_label, kind, want_variances,
+                              d_out_sums, d_out_grad_data);
+}
+
 int vqa_sample_counts(int device, const double* probs, int n_outcomes, const int64_t* shots, int64_t E,
                       uint64_t seed, uint64_t stream_id, int64_t* counts) {
     if (n_outcomes < 1 || n_outcomes > 1024) VQA_FAIL(VQA_EINVAL, "n_outcomes must be in [1, 1024] (got %d)", n_outcomes);
@@ -906,6 +936,15 @@ int vqa_mse_stats_dev(int device, void* stream, const double* d_expect, const do
                       const double* d_y, double w, const double* d_shots, const double* d_weight, double n_shots0,
                       int mode, uint64_t seed, int want_variances, double n0, int second_order, double* d_workspace,
                       double* d_out_sums, double* d_out_m0, double* d_out_grad_data) {
+    return vqa_mse_stats_shard_dev(device, stream, d_expect, d_estimates, B, P, d_y, w, d_shots, d_weight, n_shots0, mode, seed,
+                                   want_variances, n0, second_order, d_workspace, d_out_sums, d_out_m0, d_out_grad_data, 0);
+}
+
+int vqa_mse_stats_shard_dev(int device, void* stream, const double* d_expect, const double* d_estimates, int64_t B, int P,
+                            const double* d_y, double w, const double* d_shots, const double* d_weight, double n_shots0,
+                            int mode, uint64_t seed, int want_variances, double n0, int second_order, double* d_workspace,
+                            double* d_out_sums, double* d_out_m0, double* d_out_grad_data, int64_t row_offset) {
+    if (row_offset < 0) VQA_FAIL(VQA_EINVAL, "row_offset must be >= 0");
     if (B < 0 || P < 0) VQA_FAIL(VQA_EINVAL, "B and P must be >= 0");
     if (mode < 0 || mode > 3) VQA_FAIL(VQA_EINVAL, "mode must be 0 (exact), 1 (CLT), 2 (finite shots) or 3 (given estimates)");
     if (!d_out_sums) VQA_FAIL(VQA_EINVAL, "out_sums is NULL");
@@ -919,7 +958,7 @@ int vqa_mse_stats_dev(int device, void* stream, const double* d_expect, const do
     if (device < 0 || device >= count) VQA_FAIL(VQA_ENODEVICE, "device %d out of range (%d visible)", device, count);
     VQA_HIP(hipSetDevice(device));
     return mse_stats_launch((hipStream_t)stream, d_expect, d_estimates, B, P, d_y, w, d_shots, d_weight, n_shots0, mode, seed,
-                            want_variances, n0, second_order, d_workspace, d_out_sums, d_out_m0, d_out_grad_data);
+                            want_variances, n0, second_order, d_workspace, d_out_sums, d_out_m0, d_out_grad_data, row_offset);
 }
 
 int vqa_irandom_stats_dev(int device, void* stream, const double* d_expect, int n_obs, const int32_t* d_label,

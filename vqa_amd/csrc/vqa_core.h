@@ -218,15 +218,18 @@ int fill_dead_rows(hipStream_t stream, double* d_out, int64_t n_samples, int K, 
 
 // multinomial outcome counts per row, chain of binomials (kern_sample.hip)
 int sample_counts_launch(hipStream_t stream, const double* d_probs, int M, const int64_t* d_shots, int64_t E,
-                         uint64_t seed, uint64_t stream_id, int64_t* d_counts);
+                         uint64_t seed, uint64_t stream_id, int64_t* d_counts, int64_t row_offset = 0);
 
 // estimator epilogue of the regressor's oracles (kern_stats.hip)
 size_t mse_stats_workspace_bytes(int64_t B, int P);
 int mse_stats_launch(hipStream_t stream, const double* d_E, const double* d_est, int64_t B, int P, const double* d_y,
                      double w, const double* d_shots, const double* d_weight, double n_shots0, int mode, uint64_t seed,
                      int want_var, double n0, int second_order, double* d_workspace, double* d_out, double* d_m0,
-                     double* d_gd);
+                     double* d_gd, int64_t row_offset);
 
+// the classifier's gradient terms and conditional-variance estimates from class counts (kern_stats.hip)
+int class_stats_launch(hipStream_t stream, const int64_t* d_counts, const int64_t* d_shots, int64_t B, int P,
+                       const int32_t* d_label, int kind, int want_var, double* d_out, double* d_gd);
 int class_grad_launch(hipStream_t stream, const int64_t* d_counts, const int64_t* d_shots, int64_t B, int P,
                       const int32_t* d_label, const double* d_y1hot, double* d_grad);
 int irandom_stats_launch(hipStream_t stream, const double* d_expect, int n_obs, const int32_t* d_label, const double* d_y,

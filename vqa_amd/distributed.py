@@ -64,10 +64,11 @@ def sharded_mse_gradient(circuit, theta, inputs, y, w, obs, n_global=None, group
         e = torch.from_numpy(e)
     y_t = y if isinstance(y, torch.Tensor) else torch.from_numpy(np.asarray(y, np.float64)).to(e.device)
     if e.is_cuda:
-        # the library's estimator epilogue: one pass over the matrix, fixed summation order
+        # the library's estimator epilogue: one pass over the matrix, fixed summation order; the sums stay
+        # on the device for the all-reduce
         from .stats import GD, mse_stats
 
-        sums = torch.from_numpy(np.ascontiguousarray(mse_stats(e, y_t, w)[0][:, GD])).to(e.device)
+        sums = mse_stats(e, y_t, w, device_sums=True)[0][:, GD].contiguous()
     else:
         sums = mse_gradient_sums(e, y_t, w)
     distributed = dist.is_available() and dist.is_initialized()
@@ -79,3 +80,65 @@ def sharded_mse_gradient(circuit, theta, inputs, y, w, obs, n_global=None, group
     if distributed:
         all_reduce_sum(sums, group=group)
     return sums / n_global
+
+
+class BatchShard:
+    """How a target object with a process group splits one mini-batch: every rank holds the whole data
+    set, rank r evaluates the contiguous block [lo, hi) of the batch's samples, and the ranks add the
+    batch sums of their blocks with ONE all-reduce (reduce()).  The batch itself -- which samples, and
+    the seed of the device-side random streams -- is rank 0's: bcast_ints() hands it to the others, so
+    the ranks' NumPy generators need not agree."""
+
+    def __init__(self, group, n_items, device=None):
+        import torch
+        import torch.distributed as dist
+
+        self.dist, self.group = dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.n = int(n_items)
+        self.lo, self.hi = shard_bounds(self.n, self.rank, self.world)
+        # NCCL / RCCL moves device tensors only; gloo takes host tensors
+        self.device = torch.device(device if (device is not None and dist.get_backend(group) != "gloo") else "cpu")
+
+    @staticmethod
+    def of(target, n_items):
+        """The shard of `target` (an object with a .group attribute) for a batch of n_items, or None when
+        the object has no group or torch.distributed is not initialised."""
+        group = getattr(target, "group", None)
+        if group is None:
+            return None
+        import torch.distributed as dist
+
+        if not (dist.is_available() and dist.is_initialized()):
+            return None
+        dev = None
+        circ = getattr(target, "circuit", None)
+        if circ is not None and getattr(circ, "device", None) is not None and hasattr(circ, "handle"):
+            dev = f"cuda:{circ.device}"
+        return BatchShard(group, n_items, dev)
+
+    def bcast_ints(self, values):
+        """Rank 0's integer array on every rank."""
+        import torch
+
+        t = torch.as_tensor(np.asarray(values, dtype=np.int64)).to(self.device)
+        self.dist.broadcast(t, src=self.dist.get_global_rank(self.group, 0) if hasattr(self.dist, "get_global_rank") else 0,
+                            group=self.group)
+        return t.cpu().numpy()
+
+    def reduce(self, sums, per_item=None):
+        """All-reduce of the batch sums (any shape) and, in the same buffer, of a per-item vector that every
+        rank fills for its own block (the unshifted estimates of its samples).  sums / per_item: torch
+        tensors on any device or numpy arrays.  Returns (sums, per-item vector of all n items) as numpy."""
+        import torch
+
+        as_t = lambda a: a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a, np.float64))
+        s = as_t(sums).to(torch.float64)
+        dev = s.device if s.is_cuda else self.device
+        buf = torch.zeros(s.numel() + (self.n if per_item is not None else 0), dtype=torch.float64, device=dev)
+        buf[:s.numel()] = s.reshape(-1).to(dev)
+        if per_item is not None:
+            buf[s.numel() + self.lo:s.numel() + self.hi] = as_t(per_item).to(torch.float64).reshape(-1).to(dev)
+        all_reduce_sum(buf, group=self.group)
+        h = buf.cpu().numpy()
+        return h[:s.numel()].reshape(tuple(s.shape)), (h[s.numel():] if per_item is not None else None)

@@ -77,6 +77,11 @@ class myQNN_base:
         # (torch generator seeded from NumPy's) and returns only the gradient; same
         # statistics and counters, but not the reference's NumPy draw sequence
         self.device_statistics = device_statistics
+        # a torch.distributed process group (one process per GPU): the mini-batch of the gradient oracles
+        # that reduce on the device (exact mode, or device_statistics) is then split into contiguous blocks
+        # over the group's ranks and the batch sums are added with one all-reduce; every rank holds the
+        # whole data set and returns the same result.  None: one process does everything.
+        self.group = None
         self.n_c_params = len(self.circuit.get_parameters())
         self.n_params = self.n_c_params + 1  # + the re-normalisation coefficient
         self.n_qubits = n_qubits
@@ -153,6 +158,7 @@ class myQNN_base:
         d = dict(self.__dict__)
         d["_handles"] = {}  # device-resident input matrices are rebuilt on demand
         d["_z0"] = None     # holds a native handle
+        d["group"] = None   # process groups do not travel
         d["methods_for_optimization"] = {k: v.__name__ for k, v in self.methods_for_optimization.items()}
         return d
 
@@ -607,7 +613,35 @@ class myQNN_base:
         min_approx = self.min_approx_shots if option_min_approx is None else option_min_approx
         wt_dist = self._uniform_wt.copy() if option_weight is None else np.array(option_weight).copy()
         eval_ind = self._pop_mini_batch_ind(mini_batch_size)
+        sh = self._shard(len(eval_ind))
+        if sh is not None:
+            eval_ind = sh.bcast_ints(eval_ind)     # the batch is rank 0's, whatever the ranks' generators did
         return min_approx, np.array(wt_dist)[eval_ind], eval_ind, self.y_train[eval_ind]
+
+    def _shard(self, n_items):
+        """This rank's part of a batch of n_items when the object has a process group, else None."""
+        if getattr(self, "group", None) is None:
+            return None
+        from .distributed import BatchShard
+
+        return BatchShard.of(self, n_items)
+
+    def _stats(self, E, y, w, sh, **kw):
+        """Batch sums of the estimator epilogue for this rank's rows E (see stats.mse_stats), added over the
+        ranks of a sharded batch: (sums [P+1, 8] numpy, unshifted estimates of ALL samples [B] numpy or None,
+        per-sample gradient terms of this rank's rows or None).  None when the sums cannot be taken where
+        E is (the circuit does not compute on a GPU and no other implementation is plugged in)."""
+        fn = getattr(self, "_stats_fn", None)
+        if fn is None:
+            if not hasattr(E, "detach"):
+                return None
+            from .stats import mse_stats as fn
+        if sh is None:
+            S, m0, gd = fn(E, y, w, **kw)
+            return np.asarray(S), (None if m0 is None else _np(m0)), gd
+        S, m0, gd = fn(E, y[sh.lo:sh.hi], w, row_offset=sh.lo, device_sums=True, **kw)
+        S, m0 = sh.reduce(S, m0)
+        return S, m0, gd
 
     # ---- parameter-shift oracles -----------------------------------------------------------
     def MSE_grad_eval(self, params, n_shots_list, mini_batch_size=None, option_min_approx=None, option_weight=None):
@@ -652,18 +686,22 @@ class myQNN_base:
         estimate the exact value), with the same counters."""
         from .distributed import mse_gradient_sums
 
-        E = self._psr_all(params, eval_ind, keep_on_device=True)
-        B, K = int(E.shape[0]), int(E.shape[1])
-        w = float(params[-1])
-        if hasattr(E, "detach"):
-            from .stats import GD, mse_stats
+        from .stats import GD
 
-            sums, m0, _ = mse_stats(E, y_eval, w, want_m0=True)
-            grad = sums[:, GD] / B
-            e0 = m0.cpu().numpy()
+        B, K = len(eval_ind), 2 * self.n_c_params + 1
+        sh = self._shard(B)
+        rows = slice(None) if sh is None else slice(sh.lo, sh.hi)
+        E = self._psr_all(params, eval_ind[rows], keep_on_device=True)
+        w = float(params[-1])
+        out = self._stats(E, np.asarray(y_eval, dtype=float), w, sh, want_m0=True)
+        if out is not None:
+            grad, e0 = out[0][:, GD] / B, out[1]
         else:
-            grad = mse_gradient_sums(E, np.asarray(y_eval, dtype=float), w) / B
-            e0 = E[:, 0]
+            # (a circuit that computes on the host: the same sums in NumPy)
+            sums, e0 = mse_gradient_sums(E, np.asarray(y_eval, dtype=float)[rows], w), E[:, 0]
+            if sh is not None:
+                sums, e0 = sh.reduce(sums, e0)
+            grad = sums / B
         self.circuit_counter[0] += B * K
         self.call_counter[0] += B * K
         self.cache_train_pred = w * e0
@@ -689,22 +727,29 @@ class myQNN_base:
             sampled = True
         else:
             return None
-        E = self._psr_all(params, eval_ind, keep_on_device=True)
-        if not hasattr(E, "detach"):
-            return None
-        from .stats import CLT, GD, SHOTS, mse_stats
+        from .stats import CLT, GD, SHOTS
 
-        B, K = int(E.shape[0]), int(E.shape[1])
+        B, K = len(eval_ind), 2 * self.n_c_params + 1
+        sh = self._shard(B)
+        rows = slice(None) if sh is None else slice(sh.lo, sh.hi)
+        if getattr(self, "_stats_fn", None) is None and not hasattr(self.circuit, "handle"):
+            return None
+        E = self._psr_all(params, eval_ind[rows], keep_on_device=True)
         P = self.n_c_params
         seed = int(np.random.randint(0, 2 ** 31 - 1))
+        if sh is not None:
+            seed = int(sh.bcast_ints([seed])[0])
         w = float(params[-1])
         n_list = np.asarray(n_shots_list, dtype=float)
-        sums, m0, _ = mse_stats(E, y_eval, w, shots=n_list, weight=wt_dist, n_shots0=n_list[-1],
-                                mode=SHOTS if sampled else CLT, seed=seed, want_m0=True)
+        out = self._stats(E, np.asarray(y_eval, dtype=float), w, sh, shots=n_list, weight=wt_dist[rows], n_shots0=n_list[-1],
+                          mode=SHOTS if sampled else CLT, seed=seed, want_m0=True)
+        if out is None:
+            return None
+        sums, m0, _ = out
         self.circuit_counter[0] += B * K
         self.call_counter[0] += (2 if sampled else 1) * B * K           # a sampled state counts twice (myQNNs_base.py:722, 1033)
         self.shots_counter[0] += int(n_all[-1].sum() + 2 * n_all[:P].sum())
-        self.cache_train_pred = w * m0.cpu().numpy()
+        self.cache_train_pred = w * m0
         self.cache_y_train_eval = y_eval
         out = np.zeros_like(params)
         out[:] = sums[:, GD] / B
@@ -737,18 +782,27 @@ class myQNN_base:
             sampled = True
         else:
             return None
-        E = self._psr_all(params, eval_ind, keep_on_device=True)
-        if not hasattr(E, "detach"):
-            return None
-        from .stats import ALT_0, ALT_I, CLT, EV_0, EV_I, GD, GD2, GD_SQ, GIVEN, SHOTS, mse_stats
+        from .stats import ALT_0, ALT_I, CLT, EV_0, EV_I, GD, GD2, GD_SQ, GIVEN, SHOTS
 
-        B, K = int(E.shape[0]), int(E.shape[1])
+        B, K = len(eval_ind), 2 * P + 1
+        sh = self._shard(B)
+        rows = slice(None) if sh is None else slice(sh.lo, sh.hi)
+        if getattr(self, "_stats_fn", None) is None and not hasattr(self.circuit, "handle"):
+            return None
+        E = self._psr_all(params, eval_ind[rows], keep_on_device=True)
         w = float(params[-1])
         seed = int(np.random.randint(0, 2 ** 31 - 1))
+        if sh is not None:
+            seed = int(sh.bcast_ints([seed])[0])
         mode = GIVEN if _estimates is not None else SHOTS if sampled else CLT
-        S, m0, gd = mse_stats(E, y_eval, w, shots=n_list, weight=wt_dist, n_shots0=n_shots0, mode=mode, seed=seed,
-                              want_variances=True, n0=n0, second_order=bool(second_order and n0), estimates=_estimates,
-                              want_m0=True, want_grad_data=True)
+        out = self._stats(E, np.asarray(y_eval, dtype=float), w, sh, shots=n_list, weight=wt_dist[rows], n_shots0=n_shots0,
+                          mode=mode, seed=seed, want_variances=True, n0=n0, second_order=bool(second_order and n0),
+                          estimates=None if _estimates is None else _estimates[rows], want_m0=True, want_grad_data=True)
+        if out is None:
+            return None
+        # (with a process group the per-sample gradient terms 'grad_data_list' stay this rank's rows of the batch;
+        # the reference's optimizers drop the entry, vqa/VQA_optimizers/qml_optimizers.py:478)
+        S, m0, gd = out
         N_all = float((P + 1) * B)
 
         def batch_var(sum_gd2, S1, S2):
@@ -779,7 +833,7 @@ class myQNN_base:
         self.circuit_counter[0] += B * K
         self.call_counter[0] += (2 if sampled else 1) * B * K
         self.shots_counter[0] += int(nb_h.sum() + 2 * ni_h.sum())
-        self.cache_train_pred = w * m0.cpu().numpy()
+        self.cache_train_pred = w * m0
         self.cache_y_train_eval = y_eval
         return {"grad": grad, "gvar_list_EV": gvar_EV, "gvar_list_EVi": gvar_EVi, "gvar_list_EV0": gvar_EV0,
                 "gvar_list_b": gvar_b, "grad_data_list": gd}

@@ -323,6 +323,9 @@ class myQNN_classifier(myQNN_base):
     def _setup(self, mini_batch_size, option_weight):
         wt_dist = self._uniform_wt.copy() if option_weight is None else np.array(option_weight).copy()
         eval_ind = self._pop_mini_batch_ind(mini_batch_size)
+        sh = self._shard(len(eval_ind))
+        if sh is not None:
+            eval_ind = sh.bcast_ints(eval_ind)     # the batch is rank 0's
         return np.array(wt_dist)[eval_ind], eval_ind, self.y_train[eval_ind], self.y_train_1hot[eval_ind]
 
     def MSE_grad_eval(self, params, n_shots_list, option_min_approx=None, option_weight=None, mini_batch_size=None,
@@ -354,59 +357,79 @@ class myQNN_classifier(myQNN_base):
                 grad[i] = np.mean(np.sum(err * (cp / n_i[:, None] - cm / n_i[:, None]), axis=1))
         return grad
 
-    def _grad_on_device(self, params, n_shots_list, wt_dist, eval_ind, y_eval, y_1hot, partial_MSE):
-        """MSE_grad_eval with the class counts drawn where the marginals are: one multinomial per
-        (sample, shift) from the library's device sampler (myQNNs_classifier.py:607-622 for all
-        2P+1 instances of every sample at once), outcome 3 re-dealt by a second multinomial when
-        class_unbias, products and batch means on the GPU.  Same estimators, counters and shot
-        totals as the host path; the random stream is the sampler's, seeded from NumPy's.  None when
-        the circuit does not compute on a GPU."""
-        theta = np.asarray(params[:self.n_c_params], dtype=np.float64)
-        _, M = self.circuit.psr_full(theta, self._handle("train"), sel=np.asarray(eval_ind, np.int32), obs_list=[],
-                                     n_marg_bits=2)
-        if not hasattr(M, "detach"):
+    def _device_class_sums(self, params, n_shots_list, wt_dist, eval_ind, y_eval, kind, want_var=False, want_gd=False):
+        """The per-component batch sums of a classifier oracle with everything behind the marginals on the
+        GPU: one multinomial per (sample, shift) from the library's device sampler
+        (myQNNs_classifier.py:607-622 for all 2P+1 instances of every sample at once), outcome 3 re-dealt
+        by a second multinomial when class_unbias, then one kernel (vqa_class_stats_dev) that forms the
+        class frequencies, the per-sample gradient terms and variance estimates and sums them over the
+        batch.  Same estimators, counters and shot totals as the host path; the random stream is the
+        sampler's, seeded from NumPy's.  With a process group the batch is split into blocks over the
+        ranks (rows of the sampler numbered in the whole batch, so the counts do not depend on the split)
+        and the sums are added with one all-reduce.  Returns (sums [P, 4] numpy, per-sample gradient terms
+        of this rank's rows [P, B_local] device tensor or None, B), or None when the circuit does not
+        compute on a GPU."""
+        if not hasattr(self.circuit, "handle"):
             return None
         import torch
 
         from .sampling import sample_counts
+        from .stats import class_stats
 
         P = len(params)
-        B, K = int(M.shape[0]), int(M.shape[1])
+        Bg, K = len(eval_ind), 2 * P + 1
+        sh = self._shard(Bg)
+        rows = slice(None) if sh is None else slice(sh.lo, sh.hi)
+        row0 = 0 if sh is None else sh.lo
+        theta = np.asarray(params[:self.n_c_params], dtype=np.float64)
         n_all = np.floor(np.asarray(n_shots_list, dtype=float)[:P, None] * wt_dist[None, :])    # [P, B]
         n0 = np.floor(np.max(n_shots_list) * wt_dist)
+        seed = int(np.random.randint(0, 2 ** 31 - 1))
+        if sh is not None:
+            seed = int(sh.bcast_ints([seed])[0])
+        _, M = self.circuit.psr_full(theta, self._handle("train"), sel=np.asarray(eval_ind[rows], np.int32), obs_list=[],
+                                     n_marg_bits=2)
+        if not hasattr(M, "detach"):
+            return None
+        B = int(M.shape[0])
         dev = M.device
         n_inst = torch.empty((B, K), dtype=torch.int64, device=dev)
-        n_inst[:, 0] = torch.from_numpy(n0.astype(np.int64)).to(dev)
-        nt = torch.from_numpy(n_all.astype(np.int64).T.copy()).to(dev)
+        n_inst[:, 0] = torch.from_numpy(n0[rows].astype(np.int64)).to(dev)
+        nt = torch.from_numpy(n_all[:, rows].astype(np.int64).T.copy()).to(dev)
         n_inst[:, 1::2] = nt
         n_inst[:, 2::2] = nt
-        seed = int(np.random.randint(0, 2 ** 31 - 1))
-        k = sample_counts(M.reshape(B * K, 4).clamp(0.0, 1.0), n_inst.reshape(-1), seed)
+        k = sample_counts(M.reshape(B * K, 4).clamp(0.0, 1.0), n_inst.reshape(-1), seed, row_offset=row0 * K)
         if self.class_unbias:
             third = torch.full((B * K, 3), 1.0 / 3.0, dtype=torch.float64, device=dev)
-            c = k[:, :3] + sample_counts(third, k[:, 3], seed, stream_id=1)
+            c = k[:, :3] + sample_counts(third, k[:, 3], seed, stream_id=1, row_offset=row0 * K)
         else:
             c = torch.stack([k[:, 0] + k[:, 3], k[:, 1], k[:, 2]], dim=1)
-        # class frequencies, products and batch means: one kernel (vqa_class_grad_dev)
-        import ctypes as C
-
-        from . import _lib
-        counts = c.to(torch.int64).contiguous()
-        grad = torch.empty(P, dtype=torch.float64, device=dev)
-        d_lab = d_hot = None
-        if partial_MSE:
-            d_lab = torch.from_numpy(np.asarray(y_eval, dtype=np.int32)).to(dev)
-        else:
-            d_hot = torch.from_numpy(np.ascontiguousarray(y_1hot, dtype=np.float64)).to(dev)
-        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
-        _lib.check(_lib.lib().vqa_class_grad_dev(dev.index or 0, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream),
-                                                 ptr(counts), ptr(n_inst.contiguous()), B, P, ptr(d_lab), ptr(d_hot), ptr(grad)))
-        self.circuit_counter[0] += B * K
-        self.call_counter[0] += B * K
+        sums, gd = class_stats(c.reshape(B, K, 3), n_inst, np.asarray(y_eval, dtype=np.int32)[rows], P, kind,
+                               want_variances=want_var, want_grad_data=want_gd)
+        S = sums.cpu().numpy() if sh is None else sh.reduce(sums)[0]
+        self.circuit_counter[0] += Bg * K
+        self.call_counter[0] += Bg * K
         self.shots_counter[0] += int(n0.sum() + 2 * n_all.sum())
+        return S, gd, Bg
+
+    def _grad_on_device(self, params, n_shots_list, wt_dist, eval_ind, y_eval, y_1hot, partial_MSE):
+        """MSE_grad_eval on the GPU (see _device_class_sums); None when the circuit does not compute on one."""
+        from .stats import FULL_MSE, PARTIAL_MSE
+
+        got = self._device_class_sums(params, n_shots_list, wt_dist, eval_ind, y_eval, PARTIAL_MSE if partial_MSE else FULL_MSE)
+        if got is None:
+            return None
+        S, _, B = got
         out = np.zeros_like(params)
-        out[:] = grad.cpu().numpy()
+        out[:] = S[:, 0] / B
         return out
+
+    @staticmethod
+    def _ev_from_sums(S, B):
+        """Batch mean of the conditional-variance estimate, or of its fallback form where that mean is negative
+        (myQNNs_classifier.py:875-885, 1166-1168)."""
+        ev = S[:, 1] / B
+        return np.where(ev < 0, S[:, 2] / B, ev)
 
     def _estimate_MSEgrad_mean_condVar(self, pp, pp2, varpp, pm, pm2, varpm, p0, p02, varp0, y_eval_1hot=None,
                                        second_order=False, partial_MSE=True):
@@ -433,6 +456,19 @@ class myQNN_classifier(myQNN_base):
         grad = np.zeros_like(params)
         gvar_list_EV = np.zeros_like(params)
         wt_dist, eval_ind, y_eval, y_1hot = self._setup(mini_batch_size, option_weight)
+        if getattr(self, "device_statistics", False):
+            from .stats import FULL_MSE, PARTIAL_MSE
+
+            got = self._device_class_sums(params, n_shots_list, wt_dist, eval_ind, y_eval, PARTIAL_MSE if partial_MSE else FULL_MSE,
+                                          want_var=True, want_gd=True)
+            if got is not None:
+                S, gd, B = got
+                grad[:] = S[:, 0] / B
+                gvar_list_EV[:] = self._ev_from_sums(S, B)
+                z = np.zeros_like(params)
+                # (with a process group 'grad_data_list' holds this rank's rows of the batch)
+                return {"grad": grad, "gvar_list_EV": gvar_list_EV, "gvar_list_EVi": z.copy(), "gvar_list_EV0": z.copy(),
+                        "gvar_list_b": z.copy(), "grad_data_list": gd}
         grad_data_list = np.zeros((len(params), len(eval_ind)))
         M = self._psr_marginals(params, eval_ind)
         n0 = np.floor(np.max(n_shots_list) * wt_dist).astype(int)
@@ -522,6 +558,18 @@ class myQNN_classifier(myQNN_base):
         grad = np.zeros_like(params)
         gvar_list_EV = np.zeros_like(params)
         wt_dist, eval_ind, y_eval, _ = self._setup(mini_batch_size, option_weight)
+        if getattr(self, "device_statistics", False):
+            from .stats import CROSS_ENTROPY
+
+            got = self._device_class_sums(params, n_shots_list, wt_dist, eval_ind, y_eval, CROSS_ENTROPY, want_var=with_var,
+                                          want_gd=with_var)
+            if got is not None:
+                S, gd, B = got
+                grad[:] = S[:, 0] / B + L2_reg_lmd * np.asarray(params, dtype=float)
+                if with_var:
+                    gvar_list_EV[:] = self._ev_from_sums(S, B)
+                # as in the reference, grad_data_list holds the last component's per-sample values
+                return grad, gvar_list_EV, (gd[-1] if gd is not None else None)
         M = self._psr_marginals(params, eval_ind)
         n0 = np.floor(np.max(n_shots_list) * wt_dist).astype(int)
         count0 = self._success(self._draw_class_counts(M[:, 0], n0), y_eval)

@@ -17,8 +17,10 @@ import numpy as np
 from . import _lib
 
 
-def sample_counts(probs, shots, seed: int, stream_id: int = 0, device: int = 0):
-    """counts[e, :] ~ Multinomial(shots[e], probs[e, :]).
+def sample_counts(probs, shots, seed: int, stream_id: int = 0, device: int = 0, row_offset: int = 0):
+    """counts[e, :] ~ Multinomial(shots[e], probs[e, :]).  row_offset (device path): the number of the
+    first row in a longer list that several ranks share; row e draws what row e + row_offset of one
+    call over the whole list would draw.
 
     numpy inputs: host-pointer path, returns an int64 array.  torch cuda
     tensors: device path, queued on the current torch stream, returns an int64
@@ -44,8 +46,8 @@ def sample_counts(probs, shots, seed: int, stream_id: int = 0, device: int = 0):
     out = torch.empty(p.shape, dtype=torch.int64, device=dev)
     st = torch.cuda.current_stream(dev).cuda_stream
     ptr = lambda t: C.c_void_p(t.data_ptr())
-    _lib.check(L.vqa_sample_counts_dev(dev.index or 0, C.c_void_p(st), ptr(p), p.shape[1], ptr(n), p.shape[0],
-                                       seed, stream_id, ptr(out)))
+    _lib.check(L.vqa_sample_counts_shard_dev(dev.index or 0, C.c_void_p(st), ptr(p), p.shape[1], ptr(n), p.shape[0],
+                                             seed, stream_id, ptr(out), int(row_offset)))
     return out
 
 

@@ -17,9 +17,12 @@ GD, GD_SQ, EV_I, EV_0, ALT_I, ALT_0, GD2 = range(7)
 
 
 def mse_stats(E, y, w, shots=None, weight=None, n_shots0=0.0, mode=EXACT, seed=0, want_variances=False, n0=0.0,
-              second_order=False, estimates=None, want_m0=False, want_grad_data=False):
+              second_order=False, estimates=None, want_m0=False, want_grad_data=False, row_offset=0, device_sums=False):
     """E: torch cuda tensor [B, 2P+1] (may be a strided view whose rows are contiguous).  Returns
-    (sums [P+1, 8] numpy, m0 [B] tensor or None, grad_data [P+1, B] tensor or None)."""
+    (sums [P+1, 8], m0 [B] tensor or None, grad_data [P+1, B] tensor or None); the sums as a numpy array,
+    or with device_sums as the device tensor the kernel wrote (no host synchronisation: what a sharded
+    caller hands to its all-reduce).  row_offset: number of E's first row in the whole mini-batch when E
+    is one rank's shard of it (names the random streams, see vqa_mse_stats_shard_dev)."""
     import torch
 
     E = E.contiguous()
@@ -35,10 +38,10 @@ def mse_stats(E, y, w, shots=None, weight=None, n_shots0=0.0, mode=EXACT, seed=0
     gd = torch.empty((P + 1, B), dtype=torch.float64, device=dev) if want_grad_data else None
     p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
     st = torch.cuda.current_stream(dev).cuda_stream
-    _lib.check(L.vqa_mse_stats_dev(dev.index or 0, C.c_void_p(st), p(E), p(est_t), B, P, p(y_t), float(w), p(shots_t),
-                                   p(weight_t), float(n_shots0), int(mode), int(seed), int(bool(want_variances)), float(n0),
-                                   int(bool(second_order)), p(ws), p(out), p(m0), p(gd)))
-    return out.cpu().numpy(), m0, gd
+    _lib.check(L.vqa_mse_stats_shard_dev(dev.index or 0, C.c_void_p(st), p(E), p(est_t), B, P, p(y_t), float(w), p(shots_t),
+                                         p(weight_t), float(n_shots0), int(mode), int(seed), int(bool(want_variances)),
+                                         float(n0), int(bool(second_order)), p(ws), p(out), p(m0), p(gd), int(row_offset)))
+    return (out if device_sums else out.cpu().numpy()), m0, gd
 
 
 def irandom_stats(circuit, theta, inputs, obs_list, rows_sample, rows_comp_seg, rows_shots, n_list, w, M_tot, seed,
@@ -72,3 +75,27 @@ def irandom_stats(circuit, theta, inputs, obs_list, rows_sample, rows_comp_seg, 
                                                 p(d_shots), p(d_seg), p(d_n), C_, int(kind), int(bool(has_scale)),
                                                 float(w), float(M_tot), int(seed), p(out)))
     return out.cpu().numpy()
+
+
+PARTIAL_MSE, FULL_MSE, CROSS_ENTROPY = 0, 1, 2
+
+
+def class_stats(counts, shots, labels, n_params, kind, want_variances=False, want_grad_data=False):
+    """The classifier's per-component batch sums from drawn class counts (thin wrapper of
+    vqa_class_stats_dev): counts [B, 2P+1, 3] and shots [B, 2P+1] int64 cuda tensors, labels [B].
+    Returns (sums [P, 4] device tensor: gradient term, conditional-variance estimate, its fallback
+    form; per-sample gradient terms [P, B] device tensor or None)."""
+    import torch
+
+    dev = counts.device
+    B = int(shots.shape[0])
+    counts = counts.to(torch.int64).contiguous()
+    shots = shots.to(torch.int64).contiguous()
+    lab = (labels if hasattr(labels, "is_cuda") else torch.from_numpy(np.ascontiguousarray(labels, np.int32))).to(dev, torch.int32).contiguous()
+    out = torch.zeros((n_params, 4), dtype=torch.float64, device=dev)
+    gd = torch.empty((n_params, B), dtype=torch.float64, device=dev) if want_grad_data else None
+    p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    st = torch.cuda.current_stream(dev).cuda_stream
+    _lib.check(_lib.lib().vqa_class_stats_dev(dev.index or 0, C.c_void_p(st), p(counts), p(shots), B, int(n_params), p(lab),
+                                              int(kind), int(bool(want_variances)), p(out), p(gd)))
+    return out, gd
