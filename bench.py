@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="process-group backend (gloo: rehearsals of the N > 1 path)")
     ap.add_argument("--force-dist", action="store_true",
                     help="create the process group even for one rank (exercises the RCCL calls on a one-GPU box)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: the workload's batch on every GPU; strong: that batch split over the GPUs (contiguous blocks)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="every rank on cuda:0 (rehearsal of the N > 1 path on a one-GPU box; not a valid number)")
     args = ap.parse_args()
@@ -127,6 +129,13 @@ def main():
     n, d, B = WORKLOADS[args.workload]
     if args.batch:
         B = args.batch
+    B_config = B
+    if args.scaling == "strong":
+        # the same total batch on any number of GPUs: rank r takes the r-th contiguous block
+        from vqa_amd.distributed import shard_bounds
+
+        lo, hi = shard_bounds(B, rank, world)
+        B = hi - lo
     if args.engine:
         _lib.check(_lib.lib().vqa_set_engine(args.engine))
     circ = create_ibm_HEA_ansatz(n, d, seed=0, circuit_cls=lambda nq: LearningCircuit(nq, device=local_rank))
@@ -177,10 +186,11 @@ def main():
             return r
 
     timed = Timed()
+    B_global = B_config if args.scaling == "strong" else B * world
 
     def step(i=None):
         timed.i = i
-        return sharded_mse_gradient(timed, d_theta, d_in, d_y, w, z0, n_global=B * world, out_expect=d_out)
+        return sharded_mse_gradient(timed, d_theta, d_in, d_y, w, z0, n_global=B_global, out_expect=d_out)
 
     def fence():
         if use_dist:
@@ -206,7 +216,7 @@ def main():
         evals = B * K
         G, bytes_alg, flops_alg = alg_work(n, d)
         evals_per_s_kernel = evals / (kern_ms * 1e-3)
-        grads_per_s = B * world * args.steps / dt
+        grads_per_s = B_global * args.steps / dt
         res = {
             "metric": "parameter-shift gradients/sec",
             "value": grads_per_s,
@@ -216,15 +226,16 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "circuit_evals_per_sec": evals * world * args.steps / dt,
+            "circuit_evals_per_sec": B_global * K * args.steps / dt,
             "config": {
                 "workload": f"{n}-qubit IBM-HEA QNN regressor, depth {d}, {G} gates, P={P}, "
-                            f"batch {B} samples per GPU, full parameter shift ({K} evaluations per sample)",
-                "n_qubits": n, "depth": d, "batch_per_gpu": B, "n_params": P,
+                            + (f"batch {B} samples per GPU" if args.scaling == "weak" else f"batch {B_global} samples split over the GPUs")
+                            + f", full parameter shift ({K} evaluations per sample)",
+                "n_qubits": n, "depth": d, "batch_per_gpu": B, "global_batch": B_global, "n_params": P,
                 "evals_per_step_per_gpu": evals, "engine": args.engine or "auto",
                 "prefix_reuse": True,
                 # parameters whose rotations lie outside the backward light cone of the measured qubit:
@@ -294,7 +305,7 @@ def roofline(bytes_alg, flops_alg, evals, kern_ms, measured):
     ex = None if ex_valu is None else ex_valu + ex_mfma
     ex_tflops = None if ex is None else ex * per_s / 1e12
     r = {
-        "kernel": "k_reg_psr",
+        "kernel": profiled_str("kernel") or "k_reg_psr",
         # the FP64 pipe: v_fma_f64 / v_mul_f64 and, for the rotations on lane bits 4 and 5, v_mfma_f64_4x4x4
         # (on gfx950 the FP64 matrix peak equals the FP64 vector peak, 78.6 TFLOP/s, and the two share the pipe)
         "bound": "valu_fp64",
@@ -327,6 +338,26 @@ def roofline(bytes_alg, flops_alg, evals, kern_ms, measured):
         if "fp64_fma_tflops" in measured and ex_tflops is not None:
             r["frac_of_measured_peak"] = ex_tflops / measured["fp64_fma_tflops"]
     return r
+
+
+def state_passes(reset=False):
+    """(read-and-write, read-only) passes over a state that the HBM engine has launched since the last reset."""
+    import ctypes as C
+
+    from vqa_amd import _lib
+
+    rw, ro = C.c_int64(0), C.c_int64(0)
+    _lib.check(_lib.lib().vqa_state_pass_counters(C.byref(rw), C.byref(ro), int(reset)))
+    return rw.value, ro.value
+
+
+def hbm_profile(name):
+    """Per-sample figures of an HBM-engine configuration from the committed profile, or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "hbm_configs.json")) as f:
+            return json.load(f)[name]
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def profiled_str(key):
@@ -394,21 +425,36 @@ def other_configs(device):
         obs = [z_observable(n, 0)]
         c.psr_full(th, x, n_sel=min(B, 2), obs_list=obs)
         torch.cuda.synchronize()
+        state_passes(reset=True)
         t0 = time.perf_counter()
         for _ in range(reps):
             c.psr_full(th, x, n_sel=B, obs_list=obs)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / reps
+        rw, ro = state_passes()
         K = 2 * c.n_theta + 1
         out[name] = {"gradients_per_sec": B / dt, "circuit_evals_per_sec": B * K / dt, "n_params": c.n_theta,
                      "ms_per_call": 1e3 * dt}
         if n == 20:
             # FP64 flops the tiled passes execute per sample of this configuration (PMC SQ_INSTS_VALU_{FMA,MUL,ADD}_F64 of
             # tools/bench_hbm_batch.py 20 8 16, 11-qubit tiles) at the rate measured here, against the vector FP64 peak
-            flops = 8.96e10
-            out[name]["roofline"] = {"kernel": "k_tile_pass", "bound": "valu_fp64", "achieved": flops * B / dt / 1e12, "peak": 78.6,
-                                     "unit": "TFLOP/s", "frac": flops * B / dt / 78.6e12,
-                                     "executed_fp64_flops_per_sample": flops, "profile_source": "prof_r02f (PMC)"}
+            # ... the flops per state pass come from the committed profile (profiles/hbm_configs.json, written by
+            # tools/hbm_configs_profile.py from the PMC passes of tools/bench_hbm_batch.py); the passes over a state that
+            # this call made are counted by the library now: a plan that changed since the profile shows as a
+            # different count, and the figure is then left out
+            prof = hbm_profile("hea20_d8")
+            nbytes = (2 * rw + ro) * 16.0 * 2 ** n / reps
+            roof = {"kernel": "k_tile_pass", "state_passes_per_sample": (rw + ro) / reps / B,
+                    "traffic": nbytes, "hbm_achieved_GBs": nbytes / dt / 1e9, "hbm_frac": nbytes / dt / 8e12}
+            if prof and abs(prof["state_passes_per_sample"] - (rw + ro) / reps / B) < 0.5:
+                flops = prof["fp64_flops_per_sample"]
+                roof.update({"bound": "valu_fp64", "achieved": flops * B / dt / 1e12, "peak": 78.6, "unit": "TFLOP/s",
+                             "frac": flops * B / dt / 78.6e12, "executed_fp64_flops_per_sample": flops,
+                             "profile_source": prof.get("source")})
+            else:
+                roof.update({"bound": "valu_fp64", "achieved": None, "peak": 78.6, "unit": "TFLOP/s", "frac": None,
+                             "profile_source": "no committed profile of this plan"})
+            out[name]["roofline"] = roof
         del c, x
         torch.cuda.empty_cache()
     out["28-qubit VQE: RY + CZ ring depth 6, Ising ring (56 Pauli terms), full gradient"] = vqe_config(device)
@@ -460,20 +506,22 @@ def vqe_config(device, n=28, d=6):
     shots = np.full(c.n_theta, 1000)
     times = []
     for _ in range(2):
+        state_passes(reset=True)
         t0 = time.perf_counter()
         g = vqe.iEval(theta, shots)["grad"]
         torch.cuda.synchronize()
         times.append(time.perf_counter() - t0)
+    rw, ro = state_passes()
     del vqe, c
     torch.cuda.empty_cache()
     res = {"seconds_per_gradient": times[1], "first_call_seconds": times[0], "n_params": int(len(theta)),
            "shifted_evaluations_per_sec": 2 * len(theta) / times[1], "grad_norm": float(np.linalg.norm(g))}
-    if n == 28 and d == 6:
-        # passes over a state that one gradient makes (the library's own count, VQA_PLAN_DEBUG: 1211 that read and write a
-        # state, 588 measuring ones that only read) x 16 bytes x 2^28 amplitudes, against the 8 TB/s of HBM
-        nbytes = (1211 * 2 + 588) * 16.0 * 2 ** 28
-        res["roofline"] = {"kernel": "k_tile_pass", "bound": "hbm", "achieved": nbytes / times[1] / 1e9, "peak": 8000.0, "unit": "GB/s",
-                           "frac": nbytes / times[1] / 8e12, "bytes_per_gradient": nbytes}
+    # passes over a state that the timed gradient made, counted by the library (those that read and write a state,
+    # and the measuring ones that only read) x 16 bytes x 2^n amplitudes, against the 8 TB/s of HBM
+    nbytes = (rw * 2 + ro) * 16.0 * 2 ** n
+    res["roofline"] = {"kernel": "k_tile_pass", "bound": "hbm", "achieved": nbytes / times[1] / 1e9, "peak": 8000.0, "unit": "GB/s",
+                       "frac": nbytes / times[1] / 8e12, "traffic": nbytes, "state_passes_read_write": rw,
+                       "state_passes_read_only": ro}
     return res
 
 
@@ -498,16 +546,21 @@ def cpu_baseline(circ, theta, ia, P, seconds):
     t0 = time.perf_counter()
     cpu_oracle.eval_batch(circ, theta, ia, si, sp, sv, obs_list=[z0], n_threads=threads)
     dt = time.perf_counter() - t0
-    # the reference's own CPU path is qulacs + skqulacs: say whether this box has them (never installed here)
+    # the reference's own CPU path is qulacs + skqulacs: timed when this box happens to have them (never installed here)
+    ref_timing = None
     try:
         import qulacs  # noqa: F401
         import skqulacs  # noqa: F401
 
-        ref_note = ("qulacs %s present but not timed: the baseline below is the port"
-                    % getattr(qulacs, "__version__", "?"))
+        try:
+            ref_timing = reference_loop(circ, theta, P, min(seconds, 10.0))
+            ref_note = "qulacs %s present: the reference's own loop is timed beside the port" % getattr(qulacs, "__version__", "?")
+        except Exception as e:   # an API this script does not know: say so, keep the port's number
+            ref_note = f"qulacs present but its loop could not be run ({type(e).__name__}: {e}); the baseline below is the port"
     except ImportError:
         ref_note = "qulacs / skqulacs not present on this box: the reference's CPU path cannot be timed, the port is"
     return {
+        "reference_loop": ref_timing,
         "value": n_eval / dt / K,
         "unit": "gradients/s",
         "circuit_evals_per_sec": n_eval / dt,
@@ -517,6 +570,42 @@ def cpu_baseline(circ, theta, ia, P, seconds):
         "sample": f"{n_eval} circuit evaluations (first {n_s} samples of the same batch, same shifts), "
                   f"{threads} OpenMP threads, {dt:.1f} s",
     }
+
+
+def reference_loop(circ, theta, P, seconds):
+    """The reference's own evaluation loop -- skqulacs LearningCircuit.update_parameters, then per sample run(x) and
+    Observable.get_expectation_value (vqa/QNN/myQNNs_base.py:916-924 under 1381-1394) -- on the same circuit, one
+    process, for about `seconds`; only reached when qulacs and skqulacs are importable on this box."""
+    from qulacs import Observable as QObservable
+    from qulacs.gate import CZ
+    from skqulacs.circuit import LearningCircuit as SkCircuit
+
+    from vqa_amd import create_ibm_HEA_ansatz
+
+    class Adapter(SkCircuit):
+        def add_CZ_gate(self, a, b):
+            self.add_gate(CZ(a, b))
+
+    n = circ.n_qubit
+    d = P // (3 * n) - 1
+    ref = create_ibm_HEA_ansatz(n, d, seed=0, circuit_cls=Adapter)
+    obs = QObservable(n)
+    obs.add_operator(1.0, "Z 0")
+    rng = np.random.default_rng(2)
+    x = rng.uniform(0.0, np.pi, (64, n))
+    done, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        k = done % (2 * P + 1)
+        th = np.array(theta, dtype=float)
+        if k:
+            th[(k - 1) // 2] += 0.5 * np.pi if k % 2 else -0.5 * np.pi
+        ref.update_parameters(th)
+        for xi in x:
+            obs.get_expectation_value(ref.run(xi))
+        done += len(x)
+    dt = time.perf_counter() - t0
+    return {"circuit_evals_per_sec": done / dt, "gradients_per_sec": done / dt / (2 * P + 1), "cores": 1,
+            "sample": f"{done} circuit evaluations in {dt:.1f} s, one process"}
 
 
 if __name__ == "__main__":

@@ -397,6 +397,14 @@ int vqa_statevector(vqa_circuit* c, int device,
  */
 int vqa_set_engine(int engine);
 
+/*
+ * Measurement aid of the HBM streaming engine, not part of the reference interface: how many passes
+ * over a whole state the library has launched in this process since the counters were last reset --
+ * those that read and write a state, and those that only read one (measuring passes).  A pass moves
+ * 16 * 2^n bytes each way; benchmarks price a call's HBM traffic with these counts.
+ */
+int vqa_state_pass_counters(int64_t* read_write, int64_t* read_only, int reset);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1831,6 +1831,8 @@ void launch_pass(const EvalCall& call, const PlanDev& pd, size_t k, double2* st,
     const auto& p = plan.passes[k];
     if (p.sweeps.empty() || C <= 0) return;
     t_state_passes += C;
+    if (io && io->partial && !io->write_state) count_state_passes(0, C);
+    else count_state_passes(C, 0);
     const int n = call.c->n_qubits;
     TilePassArgs a;
     a.n = n;

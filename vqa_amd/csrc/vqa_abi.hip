@@ -17,6 +17,14 @@ namespace vqa {
 static thread_local char g_err[512] = "";
 static int g_engine = 0;  // 0 auto
 
+static std::mutex g_count_mu;
+static int64_t g_pass_rw = 0, g_pass_ro = 0;
+void count_state_passes(int64_t read_write, int64_t read_only) {
+    std::lock_guard<std::mutex> lk(g_count_mu);
+    g_pass_rw += read_write;
+    g_pass_ro += read_only;
+}
+
 void set_error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -488,6 +496,14 @@ int vqa_device_count(void) {
         return e == hipErrorNoDevice ? 0 : VQA_EHIP;
     }
     return count;
+}
+
+int vqa_state_pass_counters(int64_t* read_write, int64_t* read_only, int reset) {
+    std::lock_guard<std::mutex> lk(g_count_mu);
+    if (read_write) *read_write = g_pass_rw;
+    if (read_only) *read_only = g_pass_ro;
+    if (reset) g_pass_rw = g_pass_ro = 0;
+    return VQA_OK;
 }
 
 int vqa_sync(int device) {

@@ -189,6 +189,10 @@ struct FixedScratch {
     size_t bytes, used;
 };
 
+// engine 3: passes over a state launched since the process started (or the counters were last reset), those that read
+// and write a state and those that only read one (the measuring passes); see vqa_state_pass_counters
+void count_state_passes(int64_t read_write, int64_t read_only);
+
 // engines: each returns VQA_OK or an error code with set_error() called
 int lds_engine_run(const EvalCall& call);
 int lds_engine_max_qubits();
