@@ -518,6 +518,36 @@ def test_streaming_sweep_random_circuits(n, seed, tile12, monkeypatch):
     assert np.abs(np.asarray(got_m).reshape(want_m.shape) - want_m).max() < TOL
 
 
+@pytest.mark.parametrize("lanes,streams", [(None, None), (2, 2), (3, 1), (1, 4)])
+def test_streaming_sweep_groups_of_samples(lanes, streams, monkeypatch):
+    """Several samples per launch on the HBM engine (a lane of the grid per sample) and groups of samples on
+    several streams: seven samples in the library's own grouping, in groups of two on two streams (the last
+    group holds one), in groups of three on one stream and one by one on four streams; selected sample
+    indices out of order, X terms behind the Hadamard layer; every row against the oracle."""
+    from helpers import random_sweep_circuit
+    n = 14
+    if lanes is not None:
+        monkeypatch.setenv("VQA_HBM_GRID_LANES", str(lanes))
+        monkeypatch.setenv("VQA_HBM_STREAMS", str(streams))
+    set_engine("hbm")
+    c = random_sweep_circuit(LearningCircuit, n, 70, seed=21, n_theta=9)
+    rng = np.random.default_rng(21)
+    theta = rng.uniform(-3, 3, c.n_theta)
+    x = rng.uniform(-1, 1, (9, 3))
+    ia = c.input_angles(x)
+    obs = random_observables(n, seed=5, n_obs=2, max_terms=3)
+    tf = Observable(n)
+    for i in range(4):
+        tf.add_operator(0.5 + 0.1 * i, f"X {i}")
+    obs = obs + [tf]
+    sel = np.array([8, 0, 3, 3, 7, 1, 5], np.int32)
+    si, sp, sv = cpu_oracle.psr_lists(len(sel), c.n_theta, sel=sel)
+    want_e, want_m = cpu_oracle.eval_batch(c, theta, ia, si, sp, sv, obs_list=obs_tuples(obs), n_marg_bits=2)
+    got_e, got_m = c.psr_full(theta, ia, sel=sel, obs_list=obs, n_marg_bits=2)
+    assert np.abs(np.asarray(got_e).reshape(want_e.shape) - want_e).max() < TOL
+    assert np.abs(np.asarray(got_m).reshape(want_m.shape) - want_m).max() < TOL
+
+
 def _edge_circuit(n, shared):
     """Parameters with a coefficient, a parameter that drives no gate, (optionally) one shared by two
     gates, CNOT sandwiches, input gates, rotations of every axis on low, middle and top qubits."""

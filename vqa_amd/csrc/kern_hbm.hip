@@ -59,13 +59,44 @@ struct HbmCommon {
     int C;           // instances in this chunk
 };
 
-__global__ __launch_bounds__(kT) void k_init(double2* st, int64_t total, int64_t D) {
+// Several samples of a sweep in one launch: blockIdx.z is the sample's lane, and a lane's states, tables,
+// partial sums and output rows lie at fixed distances from lane 0's (all zero for a launch without lanes).
+struct LaneStride {
+    int64_t st;     // amplitudes between the states of consecutive lanes
+    int64_t tab;    // entries between their angle tables
+    int64_t part;   // doubles between their partial sums
+    int64_t inst;   // bytes between their per-instance tables (of the plan the launch runs)
+    int64_t rows;   // output rows (instances) between them; the sample number goes up by one per lane
+};
+// the lanes of the launches this thread issues: set by a sweep around a group of samples, one lane otherwise
+struct LaneGrid {
+    int n = 1;
+    LaneStride ls = { 0, 0, 0, 0, 0 };
+};
+thread_local LaneGrid t_lanes;
+inline dim3 lane_grid(dim3 g) {
+    g.z = (unsigned)t_lanes.n;
+    return g;
+}
+template <class T>
+__device__ __forceinline__ T* lane_bytes(T* p, int64_t bytes) {
+    return (T*)((char*)p + bytes * blockIdx.z);
+}
+template <class T>
+__device__ __forceinline__ const T* lane_bytes(const T* p, int64_t bytes) {
+    return (const T*)((const char*)p + bytes * blockIdx.z);
+}
+
+__global__ __launch_bounds__(kT) void k_init(double2* st, int64_t total, int64_t D, LaneStride ls) {
+    st += ls.st * blockIdx.z;
     const int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;
     if (i < total) st[i] = make_double2((i & (D - 1)) == 0 ? 1.0 : 0.0, 0.0);
 }
 
 // (cos, sin) of the half angle of every rotation gate of every instance in the chunk
-__global__ __launch_bounds__(kT) void k_angles(HbmCommon h, double2* tab) {
+__global__ __launch_bounds__(kT) void k_angles(HbmCommon h, double2* tab, LaneStride ls) {
+    tab += ls.tab * blockIdx.z;
+    h.e_base += ls.rows * blockIdx.z;
     const int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;
     if (i >= (int64_t)h.C * h.n_ops) return;
     const int ci = (int)(i / h.n_ops), g = (int)(i - (int64_t)ci * h.n_ops);
@@ -291,7 +322,10 @@ __device__ __forceinline__ int tab_slot(int e) { return e ^ (e >> 4); }
 // the product of the 1-qubit gates [begin, begin + count) for every instance, in normal form:
 // mats[(ci * M + m) * 4 ..] = (tan(phi / 2), sin(phi)) or (-s / c, s c), A0, A1, b1
 __global__ __launch_bounds__(kT) void k_mats(const TileGate* __restrict__ gates, const MatDesc* __restrict__ descs, int M,
-                                             const double2* __restrict__ tab, int n_ops, int C, double2* __restrict__ mats) {
+                                             const double2* __restrict__ tab0, int n_ops, int C, double2* __restrict__ mats0,
+                                             LaneStride ls) {
+    const double2* __restrict__ tab = tab0 + ls.tab * blockIdx.z;
+    double2* __restrict__ mats = lane_bytes(mats0, ls.inst);
     const int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;
     if (i >= (int64_t)C * M) return;
     const int ci = (int)(i / M), k = (int)(i - (int64_t)ci * M);
@@ -373,7 +407,10 @@ __device__ __forceinline__ c2 diag1_factor(const TileGate& tg, bool bit, const d
 
 // the register operations of every instance: oprec[ci * NO + o]
 __global__ __launch_bounds__(kT) void k_prep_ops(const GroupOp* __restrict__ ops, const int32_t* __restrict__ op_mat0, int NO,
-                                                 int C, const double2* __restrict__ mats, int M, OpRec* __restrict__ oprec) {
+                                                 int C, const double2* __restrict__ mats0, int M, OpRec* __restrict__ oprec0,
+                                                 LaneStride ls) {
+    const double2* __restrict__ mats = lane_bytes(mats0, ls.inst);
+    OpRec* __restrict__ oprec = lane_bytes(oprec0, ls.inst);
     const int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;
     if (i >= (int64_t)C * NO) return;
     const int ci = (int)(i / NO), o = (int)(i - (int64_t)ci * NO);
@@ -397,7 +434,10 @@ __global__ __launch_bounds__(kT) void k_prep_ops(const GroupOp* __restrict__ ops
 
 // the sweeps of every instance: swrec[ci * NS + k]
 __global__ __launch_bounds__(kT) void k_prep_sweeps(const SweepDesc* __restrict__ sweeps, int NS, int C,
-                                                    const OpRec* __restrict__ oprec, int NO, SweepRec* __restrict__ swrec) {
+                                                    const OpRec* __restrict__ oprec0, int NO, SweepRec* __restrict__ swrec0,
+                                                    LaneStride ls) {
+    const OpRec* __restrict__ oprec = lane_bytes(oprec0, ls.inst);
+    SweepRec* __restrict__ swrec = lane_bytes(swrec0, ls.inst);
     const int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;
     if (i >= (int64_t)C * NS) return;
     const int ci = (int)(i / NS), k = (int)(i - (int64_t)ci * NS);
@@ -432,8 +472,11 @@ __global__ __launch_bounds__(kT) void k_prep_sweeps(const SweepDesc* __restrict_
 // the two 64-entry phase tables of every diagonal run of every instance, without the late gates:
 // pretab[(ci * NR + run) * 128 + e], e < 64: low six tile bits = e, e >= 64: high six = e - 64
 __global__ __launch_bounds__(128) void k_prep_tab(const TileGate* __restrict__ gates, const RunDesc* __restrict__ runs, int NR,
-                                                  const double2* __restrict__ tab, int n_ops, const double2* __restrict__ mats,
-                                                  int M, double2* __restrict__ pretab) {
+                                                  const double2* __restrict__ tab0, int n_ops, const double2* __restrict__ mats0,
+                                                  int M, double2* __restrict__ pretab0, LaneStride ls) {
+    const double2* __restrict__ tab = tab0 + ls.tab * blockIdx.z;
+    const double2* __restrict__ mats = lane_bytes(mats0, ls.inst);
+    double2* __restrict__ pretab = lane_bytes(pretab0, ls.inst);
     const int run = blockIdx.x, ci = blockIdx.y, tid = threadIdx.x;
     const RunDesc rd = runs[run];
     const int half = tid >> 6, i = half ? (tid & 63) << 6 : (tid & 63);
@@ -462,8 +505,10 @@ __global__ __launch_bounds__(128) void k_prep_tab(const TileGate* __restrict__ g
 }
 
 // the late gates of every instance: xrec[ci * NX + k]
-__global__ __launch_bounds__(kT) void k_prep_x(const TileGate* __restrict__ xg, int NX, int C, const double2* __restrict__ tab,
-                                               int n_ops, XRec* __restrict__ xrec) {
+__global__ __launch_bounds__(kT) void k_prep_x(const TileGate* __restrict__ xg, int NX, int C, const double2* __restrict__ tab0,
+                                               int n_ops, XRec* __restrict__ xrec0, LaneStride ls) {
+    const double2* __restrict__ tab = tab0 + ls.tab * blockIdx.z;
+    XRec* __restrict__ xrec = lane_bytes(xrec0, ls.inst);
     const int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;
     if (i >= (int64_t)C * NX) return;
     const int ci = (int)(i / NX), k = (int)(i - (int64_t)ci * NX);
@@ -681,9 +726,16 @@ struct PassIO {
 
 // One workgroup runs the pass on one tile of one instance.
 template <int MEAS>
-__global__ __launch_bounds__(kTT, kTileWaves) void k_tile_pass(double2* __restrict__ st, const SweepRec* __restrict__ swrec,
-                                                   const OpRec* __restrict__ oprec, const double2* __restrict__ pretab,
-                                                   const XRec* __restrict__ xrec, TilePassArgs a, PassIO io) {
+__global__ __launch_bounds__(kTT, kTileWaves) void k_tile_pass(double2* __restrict__ st0, const SweepRec* __restrict__ swrec0,
+                                                   const OpRec* __restrict__ oprec0, const double2* __restrict__ pretab0,
+                                                   const XRec* __restrict__ xrec0, TilePassArgs a, PassIO io, LaneStride ls) {
+    // this workgroup's lane: its states, its tables, its partial sums
+    double2* __restrict__ st = st0 + ls.st * blockIdx.z;
+    const SweepRec* __restrict__ swrec = lane_bytes(swrec0, ls.inst);
+    const OpRec* __restrict__ oprec = lane_bytes(oprec0, ls.inst);
+    const double2* __restrict__ pretab = lane_bytes(pretab0, ls.inst);
+    const XRec* __restrict__ xrec = lane_bytes(xrec0, ls.inst);
+    const int64_t lane_st = ls.st * blockIdx.z;   // (added where a state of `io` is used: `io` itself stays as it came)
     extern __shared__ double2 tile[];
     __shared__ double2 dtab[2][128];   // the phase tables of the current diagonal run and of the next one
     const int tid = threadIdx.x;
@@ -696,7 +748,7 @@ __global__ __launch_bounds__(kTT, kTileWaves) void k_tile_pass(double2* __restri
     const int ci = io.state_first ? (int)(chunk % (uint32_t)io.n_states) : (int)(blockIdx.x >> (a.n - kTileBits));
     const uint32_t tile_no = io.state_first ? ((chunk / (uint32_t)io.n_states) << 3) | (blockIdx.x & 7) : blockIdx.x & (n_tiles - 1);
     double2* own = st + ((int64_t)ci << a.n);
-    const double2* s = ci >= io.alt_from ? io.alt_src : (ci == 0 && io.rd0) ? io.rd0 : own;
+    const double2* s = ci >= io.alt_from ? io.alt_src + lane_st : (ci == 0 && io.rd0) ? io.rd0 + lane_st : own;
     int s0 = 0;   // the first sweep this state runs
     if (io.branch && ci >= io.alt_from) {
         const BranchRec br = io.branch[ci];
@@ -704,7 +756,7 @@ __global__ __launch_bounds__(kTT, kTileWaves) void k_tile_pass(double2* __restri
         s0 = br.start;
     }
     const uint64_t snap_mask = ci == 0 ? io.snap_mask : 0;
-    double2* sout = (ci == 0 && io.wr0) ? io.wr0 : own;
+    double2* sout = (ci == 0 && io.wr0) ? io.wr0 + lane_st : own;
     const OpRec* __restrict__ my_ops = oprec + (int64_t)ci * a.n_ops_total;
     const double2* __restrict__ my_tab = pretab + (int64_t)ci * a.n_runs_total * 128;
     const XRec* __restrict__ my_x = xrec + (int64_t)ci * a.n_x_total;
@@ -762,7 +814,7 @@ __global__ __launch_bounds__(kTT, kTileWaves) void k_tile_pass(double2* __restri
         for (int si = s0; si < ((abl & 1) ? 0 : a.n_sweeps); ++si) {
             lds_barrier();   // the previous sweep's amplitudes (or the gathered tile) and the next table are in LDS
             if ((snap_mask >> si) & 1) {
-                double2* snap = io.snap + ((int64_t)__popcll(snap_mask & (((uint64_t)1 << si) - 1)) << a.n);
+                double2* snap = io.snap + lane_st + ((int64_t)__popcll(snap_mask & (((uint64_t)1 << si) - 1)) << a.n);
 #pragma unroll
                 for (int k = 0; k < kTA; ++k) snap[base | g_tid | g_k[k]] = tile[tile_slot(k * kTT + tid)];
                 lds_barrier();   // everybody has read the tile before the sweep changes it
@@ -859,7 +911,7 @@ __global__ __launch_bounds__(kTT, kTileWaves) void k_tile_pass(double2* __restri
         }
         if (MEAS) {
 #pragma unroll
-            for (int k = 0; k < kTA; ++k) pv[k] = io.F[base | g_tid | g_k[k]];   // psi, on its way during the barrier
+            for (int k = 0; k < kTA; ++k) pv[k] = io.F[lane_st + (base | g_tid | g_k[k])];   // psi, on its way during the barrier
         }
         lds_barrier();
         if (!MEAS || io.write_state) {
@@ -924,7 +976,7 @@ __global__ __launch_bounds__(kTT, kTileWaves) void k_tile_pass(double2* __restri
                 va = wave_sum(va);
                 vx = wave_sum(vx);
                 if (lane == 0) {
-                    double* out = &io.partial[(((int64_t)ci * n_tiles + tile_no) * kZBatch + t) * 2];
+                    double* out = &io.partial[ls.part * blockIdx.z + (((int64_t)ci * n_tiles + tile_no) * kZBatch + t) * 2];
                     out[0] = va;
                     out[1] = vx;
                 }
@@ -1354,7 +1406,9 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
 // once, to the thread's plain sum, and only the other entries cost work per amplitude.
 // (NZ = accumulators kept per thread: batches of up to 8 entries run with a quarter of the registers)
 template <int NZ>
-__global__ __launch_bounds__(kT) void k_zpart(const double2* st, int n, ZBatch zb, double* partial) {
+__global__ __launch_bounds__(kT) void k_zpart(const double2* st, int n, ZBatch zb, double* partial, LaneStride ls) {
+    st += ls.st * blockIdx.z;
+    partial += ls.part * blockIdx.z;
     __shared__ double red[4];
     const int64_t D = (int64_t)1 << n;
     const int ci = blockIdx.x, blk = blockIdx.y, nb = gridDim.y;
@@ -1396,7 +1450,9 @@ __global__ __launch_bounds__(kT) void k_zpart(const double2* st, int n, ZBatch z
 
 // one Pauli string with X/Y factors: Re( i^ny * sum_k (-1)^{popc(k&z)} conj(a[k^x]) a[k] )
 __global__ __launch_bounds__(kT) void k_xpart(const double2* st, int n, uint64_t z, uint64_t x,
-                                              double* partial) {
+                                              double* partial, LaneStride ls) {
+    st += ls.st * blockIdx.z;
+    partial += ls.part * blockIdx.z;
     __shared__ double red[4];
     const int64_t D = (int64_t)1 << n;
     const int ci = blockIdx.y, nb = gridDim.x;
@@ -1416,7 +1472,8 @@ __global__ __launch_bounds__(kT) void k_xpart(const double2* st, int n, uint64_t
 // stage 2: out[(e_base + ci) * stride + col0 + t] (+)= coef_t * sum_blk partial
 // expectation outputs of C instances start at 0 (NaN for an instance that names a sample or
 // parameter that does not exist); the finishing kernels add their terms
-__global__ __launch_bounds__(kT) void k_out_init(double* out, int64_t e_base, int C, int stride, EvalSpec spec) {
+__global__ __launch_bounds__(kT) void k_out_init(double* out, int64_t e_base, int C, int stride, EvalSpec spec, LaneStride ls) {
+    e_base += ls.rows * blockIdx.z;
     const int i = blockIdx.x * kT + threadIdx.x;
     if (i >= C * stride) return;
     const int ci = i / stride;
@@ -1432,7 +1489,9 @@ __global__ __launch_bounds__(kT) void k_out_init(double* out, int64_t e_base, in
 __global__ __launch_bounds__(kT) void k_finish(const double* partial, int nb, int nz, ZBatch zb,
                                                int use_coef, double xcoef, double* out,
                                                int64_t e_base, int stride, int col0, int spread,
-                                               EvalSpec spec, int t0) {
+                                               EvalSpec spec, int t0, LaneStride ls) {
+    partial += ls.part * blockIdx.z;
+    e_base += ls.rows * blockIdx.z;
     __shared__ double red[4];
     const int ci = blockIdx.x;
     bool valid;
@@ -1469,7 +1528,9 @@ __global__ __launch_bounds__(kT) void k_finish(const double* partial, int nb, in
 // (cos, sin) of the half angles for slots [0, n_slots): slots 0 and 1 unshifted, slot 2 + s
 // has the rotation of parameter ord[s] moved by pi
 __global__ __launch_bounds__(kT) void k_sweep_angles(HbmCommon h, int64_t j, const int32_t* ord, int n_slots,
-                                                     double2* tab) {
+                                                     double2* tab, LaneStride ls) {
+    j += blockIdx.z;
+    tab += ls.tab * blockIdx.z;
     const int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;
     if (i >= (int64_t)n_slots * h.n_ops) return;
     const int sl = (int)(i / h.n_ops), g = (int)(i - (int64_t)sl * h.n_ops);
@@ -1489,7 +1550,9 @@ __global__ __launch_bounds__(kT) void k_sweep_angles(HbmCommon h, int64_t j, con
 }
 
 // dst[c][k] = src[k] for c < count: one read, count writes
-__global__ __launch_bounds__(kT) void k_spawn(double2* dst, const double2* src, int64_t D, int count) {
+__global__ __launch_bounds__(kT) void k_spawn(double2* dst, const double2* src, int64_t D, int count, LaneStride ls) {
+    dst += ls.st * blockIdx.z;
+    src += ls.st * blockIdx.z;
     const int64_t k = (int64_t)blockIdx.x * kT + threadIdx.x;
     if (k >= D) return;
     const double2 v = src[k];
@@ -1502,7 +1565,10 @@ __global__ __launch_bounds__(kT) void k_spawn(double2* dst, const double2* src, 
 // run side by side read the same slice of psi)
 template <int NZ>
 __global__ __launch_bounds__(kT) void k_zpart2(const double2* f, const double2* st, int n, ZBatch zb,
-                                               double* partial) {
+                                               double* partial, LaneStride ls) {
+    f += ls.st * blockIdx.z;
+    st += ls.st * blockIdx.z;
+    partial += ls.part * blockIdx.z;
     __shared__ double red[4];
     const int64_t D = (int64_t)1 << n;
     const int ci = blockIdx.x, blk = blockIdx.y, nb = gridDim.y;
@@ -1563,7 +1629,10 @@ __global__ __launch_bounds__(kT) void k_zpart2(const double2* f, const double2* 
 
 // one Pauli string with X/Y factors for state pairs: <phi|P|phi> and Re <psi|P|phi>
 __global__ __launch_bounds__(kT) void k_xpart2(const double2* f, const double2* st, int n, uint64_t z,
-                                               uint64_t x, double* partial) {
+                                               uint64_t x, double* partial, LaneStride ls) {
+    f += ls.st * blockIdx.z;
+    st += ls.st * blockIdx.z;
+    partial += ls.part * blockIdx.z;
     __shared__ double red[4];
     const int64_t D = (int64_t)1 << n;
     const int ci = blockIdx.y, nb = gridDim.x;
@@ -1591,7 +1660,8 @@ __global__ __launch_bounds__(kT) void k_xpart2(const double2* f, const double2* 
 
 // expectation rows 2i+1 (+) and 2i+2 (-) of a sample start at c^2 * (row 0 of the sample), i = ord[ci]
 __global__ __launch_bounds__(kT) void k_out_init2(double* out, int64_t row0, const int32_t* ord, const double* ord_coef,
-                                                  double shift, int C, int stride) {
+                                                  double shift, int C, int stride, LaneStride ls) {
+    row0 += ls.rows * blockIdx.z;
     const int i = blockIdx.x * kT + threadIdx.x;
     if (i >= C * stride) return;
     const int ci = i / stride, col = i - ci * stride;
@@ -1608,7 +1678,9 @@ __global__ __launch_bounds__(kT) void k_out_init2(double* out, int64_t row0, con
 __global__ __launch_bounds__(kT) void k_finish2(const double* partial, int nb, int nz, ZBatch zb, int use_coef,
                                                 double xcoef, double* out, int64_t row0, const int32_t* ord,
                                                 const double* ord_coef, double shift, int stride, int col0,
-                                                int spread, int t0) {
+                                                int spread, int t0, LaneStride ls) {
+    partial += ls.part * blockIdx.z;
+    row0 += ls.rows * blockIdx.z;
     __shared__ double red[4];
     const int ci = blockIdx.x;
     double sn, c;
@@ -1640,7 +1712,8 @@ __global__ __launch_bounds__(kT) void k_finish2(const double* partial, int nb, i
 
 // parameters that drive no gate: both shifted rows equal the unshifted one
 __global__ __launch_bounds__(kT) void k_copy_base(double* out, int64_t row0, const int32_t* unused, int n_unused,
-                                                  int stride) {
+                                                  int stride, LaneStride ls) {
+    row0 += ls.rows * blockIdx.z;
     const int i = blockIdx.x * kT + threadIdx.x;
     if (i >= n_unused * stride) return;
     const int u = i / stride, col = i - u * stride;
@@ -1752,6 +1825,7 @@ struct PlanDev {
     void* buf = nullptr;       // plan_image_bytes(*plan)
     char* inst = nullptr;      // inst_bytes(instances): mats | oprec | pretab | xrec | swrec, each [instances][row]
     int64_t cap = 0;           // instances the tables are carved for
+    int64_t lane_inst = 0;     // bytes from one lane's tables to the next lane's (launches with lanes)
     size_t n_mats() const { return std::max<size_t>(plan->all_mats.size(), 1); }
     size_t n_ops() const { return std::max<size_t>(plan->all_ops.size(), 1); }
     size_t n_runs() const { return std::max<size_t>(plan->all_runs.size(), 1); }
@@ -1773,6 +1847,13 @@ struct PlanDev {
         return (SweepRec*)(inst + mats_bytes(cap) + ops_bytes(cap) + tab_bytes(cap) + x_bytes(cap)) + slot * n_sw();
     }
 };
+
+// the strides of a launch that reads or writes the per-instance tables of pd
+inline LaneStride lanes_of(const PlanDev& pd) {
+    LaneStride ls = t_lanes.ls;
+    ls.inst = pd.lane_inst;
+    return ls;
+}
 
 // copies the plan's tables (a plan lives as long as its circuit, so the asynchronous
 // copies may read its host images after this returns)
@@ -1805,21 +1886,21 @@ void launch_mats(const EvalCall& call, const PlanDev& pd, const double2* tab, in
     const PlanImage im = plan_image(plan, pd.buf);
     auto grid = [](int64_t tot) { return dim3((unsigned)((tot + kT - 1) / kT)); };
     if (M > 0)
-        hipLaunchKernelGGL(k_mats, grid((int64_t)C * M), dim3(kT), 0, call.stream, im.gates, im.mats, M, tab, tab_stride, C,
-                           pd.mats(slot0));
+        hipLaunchKernelGGL(k_mats, lane_grid(grid((int64_t)C * M)), dim3(kT), 0, call.stream, im.gates, im.mats, M, tab, tab_stride, C,
+                           pd.mats(slot0), lanes_of(pd));
     if (NO > 0)
-        hipLaunchKernelGGL(k_prep_ops, grid((int64_t)C * NO), dim3(kT), 0, call.stream, im.ops, im.op_mat0, NO, C,
-                           pd.mats(slot0), (int)pd.n_mats(), pd.oprec(slot0));
+        hipLaunchKernelGGL(k_prep_ops, lane_grid(grid((int64_t)C * NO)), dim3(kT), 0, call.stream, im.ops, im.op_mat0, NO, C,
+                           pd.mats(slot0), (int)pd.n_mats(), pd.oprec(slot0), lanes_of(pd));
     if (NR > 0)
-        hipLaunchKernelGGL(k_prep_tab, dim3(NR, C), dim3(128), 0, call.stream, im.gates, im.runs, NR, tab, tab_stride,
-                           pd.mats(slot0), (int)pd.n_mats(), pd.pretab(slot0));
+        hipLaunchKernelGGL(k_prep_tab, lane_grid(dim3(NR, C)), dim3(128), 0, call.stream, im.gates, im.runs, NR, tab, tab_stride,
+                           pd.mats(slot0), (int)pd.n_mats(), pd.pretab(slot0), lanes_of(pd));
     if (NX > 0)
-        hipLaunchKernelGGL(k_prep_x, grid((int64_t)C * NX), dim3(kT), 0, call.stream, im.xgates, NX, C, tab, tab_stride,
-                           pd.xrec(slot0));
+        hipLaunchKernelGGL(k_prep_x, lane_grid(grid((int64_t)C * NX)), dim3(kT), 0, call.stream, im.xgates, NX, C, tab, tab_stride,
+                           pd.xrec(slot0), lanes_of(pd));
     const int NS = (int)plan.all_sweeps.size();
     if (NS > 0)
-        hipLaunchKernelGGL(k_prep_sweeps, grid((int64_t)C * NS), dim3(kT), 0, call.stream, im.sweeps, NS, C, pd.oprec(slot0),
-                           (int)pd.n_ops(), pd.swrec(slot0));
+        hipLaunchKernelGGL(k_prep_sweeps, lane_grid(grid((int64_t)C * NS)), dim3(kT), 0, call.stream, im.sweeps, NS, C, pd.oprec(slot0),
+                           (int)pd.n_ops(), pd.swrec(slot0), lanes_of(pd));
 }
 
 thread_local int64_t t_state_passes = 0;   // states x passes launched by this thread (VQA_PLAN_DEBUG report)
@@ -1830,9 +1911,9 @@ void launch_pass(const EvalCall& call, const PlanDev& pd, size_t k, double2* st,
     const TilePlan& plan = *pd.plan;
     const auto& p = plan.passes[k];
     if (p.sweeps.empty() || C <= 0) return;
-    t_state_passes += C;
-    if (io && io->partial && !io->write_state) count_state_passes(0, C);
-    else count_state_passes(C, 0);
+    t_state_passes += (int64_t)C * t_lanes.n;
+    if (io && io->partial && !io->write_state) count_state_passes(0, (int64_t)C * t_lanes.n);
+    else count_state_passes((int64_t)C * t_lanes.n, 0);
     const int n = call.c->n_qubits;
     TilePassArgs a;
     a.n = n;
@@ -1866,11 +1947,11 @@ void launch_pass(const EvalCall& call, const PlanDev& pd, size_t k, double2* st,
     pio.state_first = (pio.F || pio.alt_from < C) && n >= 24;
     const dim3 grid((unsigned)(n_tiles * C));
     if (pio.nz > 0)
-        hipLaunchKernelGGL(k_tile_pass<1>, grid, dim3(kTT), kTileAmps * sizeof(double2), call.stream, st,
-                           pd.swrec(slot0), pd.oprec(slot0), pd.pretab(slot0), pd.xrec(slot0), a, pio);
+        hipLaunchKernelGGL(k_tile_pass<1>, lane_grid(grid), dim3(kTT), kTileAmps * sizeof(double2), call.stream, st,
+                           pd.swrec(slot0), pd.oprec(slot0), pd.pretab(slot0), pd.xrec(slot0), a, pio, lanes_of(pd));
     else
-        hipLaunchKernelGGL(k_tile_pass<0>, grid, dim3(kTT), kTileAmps * sizeof(double2), call.stream, st,
-                           pd.swrec(slot0), pd.oprec(slot0), pd.pretab(slot0), pd.xrec(slot0), a, pio);
+        hipLaunchKernelGGL(k_tile_pass<0>, lane_grid(grid), dim3(kTT), kTileAmps * sizeof(double2), call.stream, st,
+                           pd.swrec(slot0), pd.oprec(slot0), pd.pretab(slot0), pd.xrec(slot0), a, pio, lanes_of(pd));
 }
 
 void launch_all_passes(const EvalCall& call, const PlanDev& pd, double2* st, int slot0, int C) {
@@ -1882,12 +1963,12 @@ int launch_gates(const EvalCall& call, const HbmCommon& h, double2* st, double2*
     const int n = h.n, C = h.C;
     const int64_t D = (int64_t)1 << n;
     const int64_t tot = D * C;
-    hipLaunchKernelGGL(k_init, dim3((unsigned)((tot + kT - 1) / kT)), dim3(kT), 0, call.stream, st,
-                       tot, D);
+    hipLaunchKernelGGL(k_init, lane_grid(dim3((unsigned)((tot + kT - 1) / kT))), dim3(kT), 0, call.stream, st,
+                       tot, D, t_lanes.ls);
     const int64_t na = (int64_t)C * h.n_ops;
     if (na > 0)
-        hipLaunchKernelGGL(k_angles, dim3((unsigned)((na + kT - 1) / kT)), dim3(kT), 0, call.stream,
-                           h, tab);
+        hipLaunchKernelGGL(k_angles, lane_grid(dim3((unsigned)((na + kT - 1) / kT))), dim3(kT), 0, call.stream,
+                           h, tab, t_lanes.ls);
     if (pd.plan) {
         launch_mats(call, pd, tab, h.n_ops, 0, C);
         launch_all_passes(call, pd, st, 0, C);
@@ -1951,10 +2032,10 @@ int measure_states(const EvalCall& call, double2* st, int C, int64_t e0, int nb,
     if (n_obs > 0) {
         const unsigned g = (unsigned)((C * n_obs + kT - 1) / kT);
         if (pair)
-            hipLaunchKernelGGL(k_out_init2, dim3(g), dim3(kT), 0, call.stream, call.d_out_expect, pair->row0, pair->ord,
-                               pair->ord_coef, pair->shift, C, n_obs);
+            hipLaunchKernelGGL(k_out_init2, lane_grid(dim3(g)), dim3(kT), 0, call.stream, call.d_out_expect, pair->row0, pair->ord,
+                               pair->ord_coef, pair->shift, C, n_obs, t_lanes.ls);
         else
-            hipLaunchKernelGGL(k_out_init, dim3(g), dim3(kT), 0, call.stream, call.d_out_expect, e0, C, n_obs, call.spec);
+            hipLaunchKernelGGL(k_out_init, lane_grid(dim3(g)), dim3(kT), 0, call.stream, call.d_out_expect, e0, C, n_obs, call.spec, t_lanes.ls);
     }
     // Z-strings of all observables, kZBatch at a time; `f` = the unshifted state the pairs are taken with.
     // The bins of the low-bit marginal ride in the same pass over the states when they fit behind
@@ -1980,23 +2061,23 @@ int measure_states(const EvalCall& call, double2* st, int C, int64_t e0, int nb,
         if (zb.nz == 0) return;
         if (pair) {
             if (fused) {}
-            else if (zb.nz <= 8) hipLaunchKernelGGL(k_zpart2<8>, dim3(C, nb), dim3(kT), 0, call.stream, f, states, n, zb, partial);
-            else hipLaunchKernelGGL(k_zpart2<kZBatch>, dim3(C, nb), dim3(kT), 0, call.stream, f, states, n, zb, partial);
+            else if (zb.nz <= 8) hipLaunchKernelGGL(k_zpart2<8>, lane_grid(dim3(C, nb)), dim3(kT), 0, call.stream, f, states, n, zb, partial, t_lanes.ls);
+            else hipLaunchKernelGGL(k_zpart2<kZBatch>, lane_grid(dim3(C, nb)), dim3(kT), 0, call.stream, f, states, n, zb, partial, t_lanes.ls);
             if (nzs)
-                hipLaunchKernelGGL(k_finish2, dim3(C), dim3(kT), 0, call.stream, partial, nb, nzs, zb, 1, 0.0,
-                                   call.d_out_expect, pair->row0, pair->ord, pair->ord_coef, pair->shift, n_obs, 0, 0, 0);
+                hipLaunchKernelGGL(k_finish2, lane_grid(dim3(C)), dim3(kT), 0, call.stream, partial, nb, nzs, zb, 1, 0.0,
+                                   call.d_out_expect, pair->row0, pair->ord, pair->ord_coef, pair->shift, n_obs, 0, 0, 0, t_lanes.ls);
             if (nbins)
-                hipLaunchKernelGGL(k_finish2, dim3(C), dim3(kT), 0, call.stream, partial, nb, nbins, zb, 1, 0.0,
-                                   call.d_out_marginal, pair->row0, pair->ord, pair->ord_coef, pair->shift, M, 0, 1, nzs);
+                hipLaunchKernelGGL(k_finish2, lane_grid(dim3(C)), dim3(kT), 0, call.stream, partial, nb, nbins, zb, 1, 0.0,
+                                   call.d_out_marginal, pair->row0, pair->ord, pair->ord_coef, pair->shift, M, 0, 1, nzs, t_lanes.ls);
         } else {
-            if (zb.nz <= 8) hipLaunchKernelGGL(k_zpart<8>, dim3(C, nb), dim3(kT), 0, call.stream, states, n, zb, partial);
-            else hipLaunchKernelGGL(k_zpart<kZBatch>, dim3(C, nb), dim3(kT), 0, call.stream, states, n, zb, partial);
+            if (zb.nz <= 8) hipLaunchKernelGGL(k_zpart<8>, lane_grid(dim3(C, nb)), dim3(kT), 0, call.stream, states, n, zb, partial, t_lanes.ls);
+            else hipLaunchKernelGGL(k_zpart<kZBatch>, lane_grid(dim3(C, nb)), dim3(kT), 0, call.stream, states, n, zb, partial, t_lanes.ls);
             if (nzs)
-                hipLaunchKernelGGL(k_finish, dim3(C), dim3(kT), 0, call.stream, partial, nb, nzs, zb, 1, 0.0,
-                                   call.d_out_expect, e0, n_obs, 0, 0, call.spec, 0);
+                hipLaunchKernelGGL(k_finish, lane_grid(dim3(C)), dim3(kT), 0, call.stream, partial, nb, nzs, zb, 1, 0.0,
+                                   call.d_out_expect, e0, n_obs, 0, 0, call.spec, 0, t_lanes.ls);
             if (nbins)
-                hipLaunchKernelGGL(k_finish, dim3(C), dim3(kT), 0, call.stream, partial, nb, nbins, zb, 0, 0.0,
-                                   call.d_out_marginal, e0, M, 0, 1, call.spec, nzs);
+                hipLaunchKernelGGL(k_finish, lane_grid(dim3(C)), dim3(kT), 0, call.stream, partial, nb, nbins, zb, 0, 0.0,
+                                   call.d_out_marginal, e0, M, 0, 1, call.spec, nzs, t_lanes.ls);
         }
         zb.nz = 0;
     };
@@ -2018,16 +2099,16 @@ int measure_states(const EvalCall& call, double2* st, int C, int64_t e0, int nb,
         for (int t = call.obs.off[o]; t < call.obs.off[o + 1]; ++t) {
             if (call.obs.x[t] == 0 || (hl.pd.plan && call.obs.z[t] == 0)) continue;
             if (pair) {
-                hipLaunchKernelGGL(k_xpart2, dim3(nb, C), dim3(kT), 0, call.stream, pair->f, st, n,
-                                   call.obs.z[t], call.obs.x[t], partial);
-                hipLaunchKernelGGL(k_finish2, dim3(C), dim3(kT), 0, call.stream, partial, nb, 1, zb, 0,
+                hipLaunchKernelGGL(k_xpart2, lane_grid(dim3(nb, C)), dim3(kT), 0, call.stream, pair->f, st, n,
+                                   call.obs.z[t], call.obs.x[t], partial, t_lanes.ls);
+                hipLaunchKernelGGL(k_finish2, lane_grid(dim3(C)), dim3(kT), 0, call.stream, partial, nb, 1, zb, 0,
                                    call.obs.coef[t], call.d_out_expect, pair->row0, pair->ord,
-                                   pair->ord_coef, pair->shift, n_obs, o, 0, 0);
+                                   pair->ord_coef, pair->shift, n_obs, o, 0, 0, t_lanes.ls);
             } else {
-                hipLaunchKernelGGL(k_xpart, dim3(nb, C), dim3(kT), 0, call.stream, st, n,
-                                   call.obs.z[t], call.obs.x[t], partial);
-                hipLaunchKernelGGL(k_finish, dim3(C), dim3(kT), 0, call.stream, partial, nb,
-                                   1, zb, 0, call.obs.coef[t], call.d_out_expect, e0, n_obs, o, 0, call.spec, 0);
+                hipLaunchKernelGGL(k_xpart, lane_grid(dim3(nb, C)), dim3(kT), 0, call.stream, st, n,
+                                   call.obs.z[t], call.obs.x[t], partial, t_lanes.ls);
+                hipLaunchKernelGGL(k_finish, lane_grid(dim3(C)), dim3(kT), 0, call.stream, partial, nb,
+                                   1, zb, 0, call.obs.coef[t], call.d_out_expect, e0, n_obs, o, 0, call.spec, 0, t_lanes.ls);
             }
         }
     }
@@ -2042,15 +2123,15 @@ int measure_states(const EvalCall& call, double2* st, int C, int64_t e0, int nb,
                 mb.col[m] = 0;
             }
             if (pair) {
-                if (mb.nz <= 8) hipLaunchKernelGGL(k_zpart2<8>, dim3(C, nb), dim3(kT), 0, call.stream, pair->f, st, n, mb, partial);
-                else hipLaunchKernelGGL(k_zpart2<kZBatch>, dim3(C, nb), dim3(kT), 0, call.stream, pair->f, st, n, mb, partial);
-                hipLaunchKernelGGL(k_finish2, dim3(C), dim3(kT), 0, call.stream, partial, nb, mb.nz, mb, 1, 0.0,
-                                   call.d_out_marginal, pair->row0, pair->ord, pair->ord_coef, pair->shift, M, m0, 1, 0);
+                if (mb.nz <= 8) hipLaunchKernelGGL(k_zpart2<8>, lane_grid(dim3(C, nb)), dim3(kT), 0, call.stream, pair->f, st, n, mb, partial, t_lanes.ls);
+                else hipLaunchKernelGGL(k_zpart2<kZBatch>, lane_grid(dim3(C, nb)), dim3(kT), 0, call.stream, pair->f, st, n, mb, partial, t_lanes.ls);
+                hipLaunchKernelGGL(k_finish2, lane_grid(dim3(C)), dim3(kT), 0, call.stream, partial, nb, mb.nz, mb, 1, 0.0,
+                                   call.d_out_marginal, pair->row0, pair->ord, pair->ord_coef, pair->shift, M, m0, 1, 0, t_lanes.ls);
             } else {
-                if (mb.nz <= 8) hipLaunchKernelGGL(k_zpart<8>, dim3(C, nb), dim3(kT), 0, call.stream, st, n, mb, partial);
-                else hipLaunchKernelGGL(k_zpart<kZBatch>, dim3(C, nb), dim3(kT), 0, call.stream, st, n, mb, partial);
-                hipLaunchKernelGGL(k_finish, dim3(C), dim3(kT), 0, call.stream, partial, nb, mb.nz, mb, 0, 0.0,
-                                   call.d_out_marginal, e0, M, m0, 1, call.spec, 0);
+                if (mb.nz <= 8) hipLaunchKernelGGL(k_zpart<8>, lane_grid(dim3(C, nb)), dim3(kT), 0, call.stream, st, n, mb, partial, t_lanes.ls);
+                else hipLaunchKernelGGL(k_zpart<kZBatch>, lane_grid(dim3(C, nb)), dim3(kT), 0, call.stream, st, n, mb, partial, t_lanes.ls);
+                hipLaunchKernelGGL(k_finish, lane_grid(dim3(C)), dim3(kT), 0, call.stream, partial, nb, mb.nz, mb, 0, 0.0,
+                                   call.d_out_marginal, e0, M, m0, 1, call.spec, 0, t_lanes.ls);
             }
         }
     }
@@ -2059,7 +2140,7 @@ int measure_states(const EvalCall& call, double2* st, int C, int64_t e0, int nb,
         double2* hs = st;
         if (!pair && hl.alt) {
             const int64_t D = (int64_t)1 << n;
-            hipLaunchKernelGGL(k_spawn, dim3((unsigned)((D + kT - 1) / kT)), dim3(kT), 0, call.stream, hl.alt, st, D, 1);
+            hipLaunchKernelGGL(k_spawn, lane_grid(dim3((unsigned)((D + kT - 1) / kT))), dim3(kT), 0, call.stream, hl.alt, st, D, 1, t_lanes.ls);
             hs = hl.alt;
         }
         const bool hf = fu && fu->h;
@@ -2179,7 +2260,7 @@ void fuse_plan(const EvalCall& call, const HLayer& hl, int64_t n_tiles, FuseInfo
 
 }  // namespace
 
-static int chunk_plan(const EvalCall& call, double frac, size_t cap_bytes, int64_t& Cmax, int& nb) {
+static int chunk_plan(const EvalCall& call, double frac, size_t cap_bytes, int64_t& Cmax, int& nb, int64_t* fit = nullptr) {
     const int n = call.c->n_qubits;
     const int64_t D = (int64_t)1 << n;
     size_t free_b = 0, total_b = 0;
@@ -2190,9 +2271,13 @@ static int chunk_plan(const EvalCall& call, double frac, size_t cap_bytes, int64
     size_t budget = std::min<size_t>(cap_bytes, (size_t)(frac * (double)free_b));
     Cmax = (int64_t)(budget / ((size_t)D * sizeof(double2)));
     if (Cmax < 1) VQA_FAIL(VQA_ENOMEM, "not enough free device memory for one %d-qubit state", n);
+    if (fit) *fit = Cmax;   // the states the budget holds; Cmax: the most a launch runs side by side
     Cmax = std::min<int64_t>(Cmax, 4096);
     // (tests: a small cap makes a sweep run in several chunks of parameters on registers whose states would all fit)
-    if (const char* cap = getenv("VQA_HBM_MAX_STATES")) Cmax = std::min<int64_t>(Cmax, std::max(atoi(cap), 1));
+    if (const char* cap = getenv("VQA_HBM_MAX_STATES")) {
+        Cmax = std::min<int64_t>(Cmax, std::max(atoi(cap), 1));
+        if (fit) *fit = Cmax;
+    }
     nb = (int)std::min<int64_t>(1024, std::max<int64_t>(1, D / (kT * 4)));
     return VQA_OK;
 }
@@ -2336,7 +2421,8 @@ int HBM_FN(hbm_engine_sweep)(const EvalCall& call, int n_samples) {
     // behind them the unshifted final state with the Hadamard layer applied (when in use) and the
     // second place of the running state (a pass reads it in one place and writes it to the other,
     // so that the states that branch off in the same launch read it as it was)
-    int rc = chunk_plan(call, 0.6, (size_t)200 << 30, Cmax, nb);
+    int64_t fit_states = 0;
+    int rc = chunk_plan(call, 0.6, (size_t)200 << 30, Cmax, nb, &fit_states);
     if (rc) return rc;
     FuseInfo fu;
     PassIO fio;
@@ -2383,36 +2469,45 @@ int HBM_FN(hbm_engine_sweep)(const EvalCall& call, int n_samples) {
     const int C = (int)std::min<int64_t>(Cmax - 3 - n_alt - n_snap, std::max(m, 1));
     // Lanes.  The samples of a sweep are independent, and one sample is a chain of a few dozen launches,
     // many of them small (a single state, or the few states of an early pass).  When the states of
-    // several samples fit side by side (every parameter in one chunk), sample j runs in lane j mod L: a
-    // lane has its own states and tables and its own stream (lane 0 the call's), so that the launches of
-    // different samples fill the GPU together.
+    // several samples fit side by side (every parameter in one chunk), a launch runs a GROUP of samples,
+    // one per lane of its grid (blockIdx.z): a lane has its own states and tables at fixed distances from
+    // lane 0's.  Groups in turn go round-robin to a few streams (stream 0 the call's), each with lanes of
+    // its own, so that the small launches of one group run beside the large ones of another.
     const int64_t per_lane = (int64_t)C + 3 + n_alt + n_snap;
-    int n_lanes = 1;
+    int n_lanes = 1;   // streams
+    int G = 1;         // samples per launch
     hipStream_t side_stream[3];
     hipEvent_t side_done[3], side_fork = nullptr;
-    // (measured: +39 % / +30 % at 15 / 16 qubits, where the host's launch rate then binds; nothing from 18 on, -5 % at 22)
-    if (C >= m && n_samples > 1 && n <= 20 && !getenv("VQA_HBM_ONE_LANE")) {
-        const int want = (int)std::min<int64_t>({ 4, (int64_t)n_samples, Cmax / per_lane });
+    if (C >= m && n_samples > 1 && !getenv("VQA_HBM_ONE_LANE")) {
+        const int64_t fit = fit_states / per_lane;
+        // (measured at depth 8, 15 / 16 / 17 / 18 / 20 qubits: +40 / +19 / +10 / +5 / +1 % over one sample per launch on four streams)
+        int want_g = n <= 17 ? 16 : n <= 20 ? 8 : 1, want_s = n <= 20 ? 2 : 1;
+        if (const char* e = getenv("VQA_HBM_GRID_LANES")) want_g = std::max(atoi(e), 1);
+        if (const char* e = getenv("VQA_HBM_STREAMS")) want_s = std::min(std::max(atoi(e), 1), 4);
+        G = (int)std::max<int64_t>(1, std::min<int64_t>({ want_g, (int64_t)n_samples, fit }));
+        const int64_t groups = ((int64_t)n_samples + G - 1) / G;
+        const int want = (int)std::min<int64_t>({ want_s, groups, fit / G });
         if (want > 1) n_lanes = 1 + call_side_streams(call, want - 1, side_stream, side_done, &side_fork);
     }
+    const int n_slots = n_lanes * G;   // lanes of states and tables in the workspace
     Carver cv;
     const size_t st_bytes = pad256((size_t)per_lane * D * sizeof(double2));
-    const size_t o_st = cv.add(st_bytes * n_lanes);
+    const size_t o_st = cv.add(st_bytes * n_slots);
     const size_t o_branch = cv.add((size_t)std::max(m, 1) * sizeof(BranchRec));
     const size_t tab_bytes = pad256((size_t)(C + 2) * n_ops * sizeof(double2));
-    const size_t o_tab = cv.add(tab_bytes * n_lanes);
+    const size_t o_tab = cv.add(tab_bytes * n_slots);
     const size_t nb_part = std::max<size_t>(nb, (fu.main || fu.h) ? (size_t)fu.n_tiles : 0);
     const size_t part_bytes = pad256((size_t)C * nb_part * kZBatch * 2 * sizeof(double));
-    const size_t o_part = cv.add(part_bytes * n_lanes);
+    const size_t o_part = cv.add(part_bytes * n_slots);
     const size_t o_gate = cv.add(pd.image_bytes());
     const size_t inst_bytes = pad256(pd.inst_bytes(C + 2));
-    const size_t o_inst = cv.add(inst_bytes * n_lanes);
+    const size_t o_inst = cv.add(inst_bytes * n_slots);
     const size_t o_ord = cv.add((size_t)std::max(m, 1) * sizeof(int32_t));
     const size_t o_coef = cv.add((size_t)std::max(m, 1) * sizeof(double));
     const size_t o_unused = cv.add((size_t)std::max(n_unused, 1) * sizeof(int32_t));
     const size_t o_hgate = cv.add(hl.pd.plan ? hl.pd.image_bytes() : 0);
     const size_t hinst_bytes = pad256(hl.pd.plan ? hl.pd.inst_bytes(C) : 0);
-    const size_t o_hinst = cv.add(hinst_bytes * n_lanes);
+    const size_t o_hinst = cv.add(hinst_bytes * n_slots);
     void* ws = nullptr;
     rc = call_workspace(call, cv.total, &ws);
     if (rc) return rc;
@@ -2483,19 +2578,31 @@ int HBM_FN(hbm_engine_sweep)(const EvalCall& call, int n_samples) {
     h.input = call.d_input;
     h.spec = call.spec;
     h.C = 1;
-    for (int64_t j = 0; j < n_samples; ++j) {
+    struct LaneReset {
+        ~LaneReset() { t_lanes = LaneGrid(); }
+    } lane_reset;
+    for (int64_t j = 0, group = 0; j < n_samples; j += G, ++group) {
+        // samples j .. j + lanes - 1 in one chain of launches; the pointers below are lane 0's
         const int64_t row0 = j * K;
-        // this sample's lane: its stream, states and tables
-        const int lane = (int)(j % n_lanes);
+        t_lanes.n = (int)std::min<int64_t>(G, n_samples - j);
+        t_lanes.ls = LaneStride{ (int64_t)(st_bytes / sizeof(double2)), (int64_t)(tab_bytes / sizeof(double2)),
+                                 (int64_t)(part_bytes / sizeof(double)), 0, (int64_t)K };
+        // the group's stream, states and tables
+        const int lane = (int)(group % n_lanes);
+        const size_t slot = (size_t)lane * G;
         EvalCall call = call0;
         if (lane > 0) call.stream = side_stream[lane - 1];
         PlanDev pd = pd0;
-        pd.carve(w + o_inst + inst_bytes * lane, C + 2);
+        pd.carve(w + o_inst + inst_bytes * slot, C + 2);
+        pd.lane_inst = (int64_t)inst_bytes;
         HLayer hl = hl0;
-        if (hl.pd.plan) hl.pd.carve(w + o_hinst + hinst_bytes * lane, C);
-        double2* st = (double2*)(w + o_st + st_bytes * lane);
-        double2* tab = (double2*)(w + o_tab + tab_bytes * lane);
-        double* partial = (double*)(w + o_part + part_bytes * lane);
+        if (hl.pd.plan) {
+            hl.pd.carve(w + o_hinst + hinst_bytes * slot, C);
+            hl.pd.lane_inst = (int64_t)hinst_bytes;
+        }
+        double2* st = (double2*)(w + o_st + st_bytes * slot);
+        double2* tab = (double2*)(w + o_tab + tab_bytes * slot);
+        double* partial = (double*)(w + o_part + part_bytes * slot);
         double2* F = st;
         double2* R = st + D;
         double2* S = st + 2 * D;
@@ -2504,17 +2611,17 @@ int HBM_FN(hbm_engine_sweep)(const EvalCall& call, int n_samples) {
         double2* snap = st + (int64_t)(C + 3 + n_alt) * D;   // late branching: the running state in front of the branching sweeps of a pass
         // the unshifted circuit: row 0 of the sample (NaN when the sample index is invalid)
         h.e_base = row0;
-        hipLaunchKernelGGL(k_init, dim3(gD), dim3(kT), 0, call.stream, F, D, D);
+        hipLaunchKernelGGL(k_init, lane_grid(dim3(gD)), dim3(kT), 0, call.stream, F, D, D, t_lanes.ls);
         if (m > 0) {
             // the tables of the first chunk of parameters hold the unshifted circuit's in row 0
             const int cnt = std::min(C, m);
             const int64_t na = (int64_t)(cnt + 2) * h.n_ops;
-            hipLaunchKernelGGL(k_sweep_angles, dim3((unsigned)((na + kT - 1) / kT)), dim3(kT), 0, call.stream, h, j, d_ord,
-                               cnt + 2, tab);
+            hipLaunchKernelGGL(k_sweep_angles, lane_grid(dim3((unsigned)((na + kT - 1) / kT))), dim3(kT), 0, call.stream, h, j, d_ord,
+                               cnt + 2, tab, t_lanes.ls);
             launch_mats(call, pd, tab, h.n_ops, 0, cnt + 2);
         } else {
             if (h.n_ops > 0)
-                hipLaunchKernelGGL(k_angles, dim3((unsigned)((h.n_ops + kT - 1) / kT)), dim3(kT), 0, call.stream, h, tab);
+                hipLaunchKernelGGL(k_angles, lane_grid(dim3((unsigned)((h.n_ops + kT - 1) / kT))), dim3(kT), 0, call.stream, h, tab, t_lanes.ls);
             launch_mats(call, pd, tab, h.n_ops, 0, 1);
         }
         for (size_t k = 0; k < n_pass; ++k) {
@@ -2542,17 +2649,17 @@ int HBM_FN(hbm_engine_sweep)(const EvalCall& call, int n_samples) {
         }
         if (n_unused > 0) {
             if (call.obs.n_obs > 0)
-                hipLaunchKernelGGL(k_copy_base, dim3((unsigned)((n_unused * call.obs.n_obs + kT - 1) / kT)), dim3(kT), 0,
-                                   call.stream, call.d_out_expect, row0, d_unused, n_unused, call.obs.n_obs);
+                hipLaunchKernelGGL(k_copy_base, lane_grid(dim3((unsigned)((n_unused * call.obs.n_obs + kT - 1) / kT))), dim3(kT), 0,
+                                   call.stream, call.d_out_expect, row0, d_unused, n_unused, call.obs.n_obs, t_lanes.ls);
             if (call.n_marg_bits > 0) {
                 const int M = 1 << call.n_marg_bits;
-                hipLaunchKernelGGL(k_copy_base, dim3((unsigned)((n_unused * M + kT - 1) / kT)), dim3(kT), 0,
-                                   call.stream, call.d_out_marginal, row0, d_unused, n_unused, M);
+                hipLaunchKernelGGL(k_copy_base, lane_grid(dim3((unsigned)((n_unused * M + kT - 1) / kT))), dim3(kT), 0,
+                                   call.stream, call.d_out_marginal, row0, d_unused, n_unused, M, t_lanes.ls);
             }
         }
         if (m == 0) continue;
         // the parameters, a chunk of slots at a time, in the order of the passes that hold their rotations
-        if (!keep_all) hipLaunchKernelGGL(k_init, dim3(gD), dim3(kT), 0, call.stream, R, D, D);
+        if (!keep_all) hipLaunchKernelGGL(k_init, lane_grid(dim3(gD)), dim3(kT), 0, call.stream, R, D, D, t_lanes.ls);
         double2* Rcur = R;
         size_t rpass = 0;
         for (int a = 0; a < m; a += C) {
@@ -2560,8 +2667,8 @@ int HBM_FN(hbm_engine_sweep)(const EvalCall& call, int n_samples) {
             const size_t k0 = (size_t)ord_pass[a], k1 = (size_t)ord_pass[a + cnt - 1];
             if (a > 0) {
                 const int64_t na = (int64_t)(cnt + 2) * h.n_ops;
-                hipLaunchKernelGGL(k_sweep_angles, dim3((unsigned)((na + kT - 1) / kT)), dim3(kT), 0, call.stream, h, j,
-                                   d_ord + a, cnt + 2, tab);
+                hipLaunchKernelGGL(k_sweep_angles, lane_grid(dim3((unsigned)((na + kT - 1) / kT))), dim3(kT), 0, call.stream, h, j,
+                                   d_ord + a, cnt + 2, tab, t_lanes.ls);
                 launch_mats(call, pd, tab, h.n_ops, 0, cnt + 2);
             }
             for (; !keep_all && rpass < k0; ++rpass) launch_pass(call, pd, rpass, Rcur, 1, 1);
@@ -2647,9 +2754,9 @@ int HBM_FN(hbm_engine_sweep)(const EvalCall& call, int n_samples) {
     VQA_HIP(hipGetLastError());
     if (getenv("VQA_PLAN_DEBUG")) {
         fprintf(stderr, "[vqa] sweep of %d samples: %d live parameters, %zu passes, %lld state passes in all (%.1f per sample); "
-                "%d parameter slots per chunk, %d places for branching points%s, %d lanes\n",
+                "%d parameter slots per chunk, %d places for branching points%s, %d samples per launch on %d streams\n",
                 n_samples, m, n_pass, (long long)t_state_passes, (double)t_state_passes / std::max(n_samples, 1), C, n_snap,
-                keep_all ? " (all passes)" : "", n_lanes);
+                keep_all ? " (all passes)" : "", G, n_lanes);
         for (size_t k = 0; k < n_pass; ++k) {
             const auto& p = plan.passes[k];
             int nb_ = 0, skip = 0;
