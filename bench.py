@@ -439,7 +439,7 @@ def other_configs(device):
             # FP64 flops the tiled passes execute per sample of this configuration (PMC SQ_INSTS_VALU_{FMA,MUL,ADD}_F64 of
             # tools/bench_hbm_batch.py 20 8 16, 11-qubit tiles) at the rate measured here, against the vector FP64 peak
             # ... the flops per state pass come from the committed profile (profiles/hbm_configs.json, written by
-            # tools/hbm_configs_profile.py from the PMC passes of tools/bench_hbm_batch.py); the passes over a state that
+            # tools/hbm_configs_profile.py from the PMC passes of tools/prof_hbm_batch.sh); the passes over a state that
             # this call made are counted by the library now: a plan that changed since the profile shows as a
             # different count, and the figure is then left out
             prof = hbm_profile("hea20_d8")
@@ -451,6 +451,11 @@ def other_configs(device):
                 roof.update({"bound": "valu_fp64", "achieved": flops * B / dt / 1e12, "peak": 78.6, "unit": "TFLOP/s",
                              "frac": flops * B / dt / 78.6e12, "executed_fp64_flops_per_sample": flops,
                              "profile_source": prof.get("source")})
+                if prof.get("hbm_bytes_per_sample"):
+                    # HBM bytes of the same profile (FETCH_SIZE + WRITE_SIZE passes) at the rate measured here
+                    roof.update({"traffic_pmc": prof["hbm_bytes_per_sample"] * B,
+                                 "hbm_pmc_GBs": prof["hbm_bytes_per_sample"] * B / dt / 1e9,
+                                 "hbm_pmc_frac": prof["hbm_bytes_per_sample"] * B / dt / 8e12})
             else:
                 roof.update({"bound": "valu_fp64", "achieved": None, "peak": 78.6, "unit": "TFLOP/s", "frac": None,
                              "profile_source": "no committed profile of this plan"})

@@ -20,8 +20,14 @@ theta = torch.from_numpy(rng.uniform(0, 2 * np.pi, c.n_theta)).cuda()
 obs = [z_observable(n, 0)]
 c.psr_full(theta, x, n_sel=1, obs_list=obs)
 torch.cuda.synchronize()
+import ctypes  # noqa: E402
+from vqa_amd import _lib  # noqa: E402
+rw, ro = ctypes.c_int64(0), ctypes.c_int64(0)
+_lib.check(_lib.lib().vqa_state_pass_counters(ctypes.byref(rw), ctypes.byref(ro), 1))
 t0 = time.perf_counter()
 c.psr_full(theta, x, n_sel=B, obs_list=obs)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
+_lib.check(_lib.lib().vqa_state_pass_counters(ctypes.byref(rw), ctypes.byref(ro), 0))
+print(f"{(rw.value + ro.value) / B:.1f} state passes per sample ({rw.value / B:.1f} read and write, {ro.value / B:.1f} read only)", flush=True)
 print(f"n={n} d={d}: {B} samples in {dt * 1e3:.1f} ms = {dt / B * 1e3:.2f} ms per sample, {B / dt:.1f} gradients/s", flush=True)
