@@ -724,18 +724,20 @@ struct PassIO {
     int32_t bin[kZBatch];     // < 0: Z-string z (a sign); >= 0: the indicator of (index & z) == bin
 };
 
-// One workgroup runs the pass on one tile of one instance.
-template <int MEAS>
+// One workgroup runs the pass on one tile of one instance.  (LANES = 0: a launch without lanes; it keeps the
+// code of the kernel as it is without them, which runs a 28-qubit pass a tenth faster.)
+template <int MEAS, int LANES>
 __global__ __launch_bounds__(kTT, kTileWaves) void k_tile_pass(double2* __restrict__ st0, const SweepRec* __restrict__ swrec0,
                                                    const OpRec* __restrict__ oprec0, const double2* __restrict__ pretab0,
                                                    const XRec* __restrict__ xrec0, TilePassArgs a, PassIO io, LaneStride ls) {
     // this workgroup's lane: its states, its tables, its partial sums
-    double2* __restrict__ st = st0 + ls.st * blockIdx.z;
-    const SweepRec* __restrict__ swrec = lane_bytes(swrec0, ls.inst);
-    const OpRec* __restrict__ oprec = lane_bytes(oprec0, ls.inst);
-    const double2* __restrict__ pretab = lane_bytes(pretab0, ls.inst);
-    const XRec* __restrict__ xrec = lane_bytes(xrec0, ls.inst);
-    const int64_t lane_st = ls.st * blockIdx.z;   // (added where a state of `io` is used: `io` itself stays as it came)
+    double2* __restrict__ st = LANES ? st0 + ls.st * blockIdx.z : st0;
+    const SweepRec* __restrict__ swrec = LANES ? lane_bytes(swrec0, ls.inst) : swrec0;
+    const OpRec* __restrict__ oprec = LANES ? lane_bytes(oprec0, ls.inst) : oprec0;
+    const double2* __restrict__ pretab = LANES ? lane_bytes(pretab0, ls.inst) : pretab0;
+    const XRec* __restrict__ xrec = LANES ? lane_bytes(xrec0, ls.inst) : xrec0;
+    const int64_t lane_st = LANES ? ls.st * blockIdx.z : 0;   // (added where a state of `io` is used: `io` itself stays as it came)
+    const int64_t lane_part = LANES ? ls.part * blockIdx.z : 0;
     extern __shared__ double2 tile[];
     __shared__ double2 dtab[2][128];   // the phase tables of the current diagonal run and of the next one
     const int tid = threadIdx.x;
@@ -976,7 +978,7 @@ __global__ __launch_bounds__(kTT, kTileWaves) void k_tile_pass(double2* __restri
                 va = wave_sum(va);
                 vx = wave_sum(vx);
                 if (lane == 0) {
-                    double* out = &io.partial[ls.part * blockIdx.z + (((int64_t)ci * n_tiles + tile_no) * kZBatch + t) * 2];
+                    double* out = &io.partial[lane_part + (((int64_t)ci * n_tiles + tile_no) * kZBatch + t) * 2];
                     out[0] = va;
                     out[1] = vx;
                 }
@@ -1870,10 +1872,9 @@ int upload_plan(const EvalCall& call, const PlanDev& pd) {
     VQA_HIP(up(im.mats, plan.all_mats.data(), plan.all_mats.size() * sizeof(MatDesc)));
     VQA_HIP(up(im.runs, plan.all_runs.data(), plan.all_runs.size() * sizeof(RunDesc)));
     VQA_HIP(up(im.sweeps, plan.all_sweeps.data(), plan.all_sweeps.size() * sizeof(SweepDesc)));
-    VQA_HIP(hipFuncSetAttribute((const void*)k_tile_pass<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                kTileAmps * (int)sizeof(double2)));
-    VQA_HIP(hipFuncSetAttribute((const void*)k_tile_pass<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                kTileAmps * (int)sizeof(double2)));
+    for (const void* fn : { (const void*)k_tile_pass<0, 0>, (const void*)k_tile_pass<1, 0>, (const void*)k_tile_pass<0, 1>,
+                            (const void*)k_tile_pass<1, 1> })
+        VQA_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kTileAmps * (int)sizeof(double2)));
     return VQA_OK;
 }
 
@@ -1946,12 +1947,10 @@ void launch_pass(const EvalCall& call, const PlanDev& pd, size_t k, double2* st,
     pio.n_states = C;
     pio.state_first = (pio.F || pio.alt_from < C) && n >= 24;
     const dim3 grid((unsigned)(n_tiles * C));
-    if (pio.nz > 0)
-        hipLaunchKernelGGL(k_tile_pass<1>, lane_grid(grid), dim3(kTT), kTileAmps * sizeof(double2), call.stream, st,
-                           pd.swrec(slot0), pd.oprec(slot0), pd.pretab(slot0), pd.xrec(slot0), a, pio, lanes_of(pd));
-    else
-        hipLaunchKernelGGL(k_tile_pass<0>, lane_grid(grid), dim3(kTT), kTileAmps * sizeof(double2), call.stream, st,
-                           pd.swrec(slot0), pd.oprec(slot0), pd.pretab(slot0), pd.xrec(slot0), a, pio, lanes_of(pd));
+    auto* kern = pio.nz > 0 ? (t_lanes.n > 1 ? k_tile_pass<1, 1> : k_tile_pass<1, 0>)
+                            : (t_lanes.n > 1 ? k_tile_pass<0, 1> : k_tile_pass<0, 0>);
+    hipLaunchKernelGGL(kern, lane_grid(grid), dim3(kTT), kTileAmps * sizeof(double2), call.stream, st, pd.swrec(slot0),
+                       pd.oprec(slot0), pd.pretab(slot0), pd.xrec(slot0), a, pio, lanes_of(pd));
 }
 
 void launch_all_passes(const EvalCall& call, const PlanDev& pd, double2* st, int slot0, int C) {
@@ -2269,6 +2268,11 @@ static int chunk_plan(const EvalCall& call, double frac, size_t cap_bytes, int64
     free_b += call_workspace_held(call);
     // state budget: a share of what is free now
     size_t budget = std::min<size_t>(cap_bytes, (size_t)(frac * (double)free_b));
+    // (A workspace that is nearly as large as the budget is kept as it is: growing it by a state would free and
+    // allocate the whole of it again, and memory that has been in use before is cleared by the driver when it is
+    // handed out -- seconds for a hundred GB.  A sixteenth of it is left for the tables beside the states.)
+    const size_t held = call_workspace_held(call);
+    if (held - held / 16 >= budget - budget / 8) budget = std::min(budget, held - held / 16);
     Cmax = (int64_t)(budget / ((size_t)D * sizeof(double2)));
     if (Cmax < 1) VQA_FAIL(VQA_ENOMEM, "not enough free device memory for one %d-qubit state", n);
     if (fit) *fit = Cmax;   // the states the budget holds; Cmax: the most a launch runs side by side
