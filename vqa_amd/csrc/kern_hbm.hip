@@ -724,8 +724,8 @@ struct PassIO {
     int32_t bin[kZBatch];     // < 0: Z-string z (a sign); >= 0: the indicator of (index & z) == bin
 };
 
-// One workgroup runs the pass on one tile of one instance.  (LANES = 0: a launch without lanes; it keeps the
-// code of the kernel as it is without them, which runs a 28-qubit pass a tenth faster.)
+// One workgroup runs the pass on one tile of one instance.  (LANES = 0: a launch without lanes keeps
+// the kernel's code as it is without them.)
 template <int MEAS, int LANES>
 __global__ __launch_bounds__(kTT, kTileWaves) void k_tile_pass(double2* __restrict__ st0, const SweepRec* __restrict__ swrec0,
                                                    const OpRec* __restrict__ oprec0, const double2* __restrict__ pretab0,
@@ -1947,8 +1947,9 @@ void launch_pass(const EvalCall& call, const PlanDev& pd, size_t k, double2* st,
     pio.n_states = C;
     pio.state_first = (pio.F || pio.alt_from < C) && n >= 24;
     const dim3 grid((unsigned)(n_tiles * C));
-    auto* kern = pio.nz > 0 ? (t_lanes.n > 1 ? k_tile_pass<1, 1> : k_tile_pass<1, 0>)
-                            : (t_lanes.n > 1 ? k_tile_pass<0, 1> : k_tile_pass<0, 0>);
+    const bool lk = t_lanes.n > 1;
+    auto* kern = pio.nz > 0 ? (lk ? k_tile_pass<1, 1> : k_tile_pass<1, 0>)
+                            : (lk ? k_tile_pass<0, 1> : k_tile_pass<0, 0>);
     hipLaunchKernelGGL(kern, lane_grid(grid), dim3(kTT), kTileAmps * sizeof(double2), call.stream, st, pd.swrec(slot0),
                        pd.oprec(slot0), pd.pretab(slot0), pd.xrec(slot0), a, pio, lanes_of(pd));
 }
