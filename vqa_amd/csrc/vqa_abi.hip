@@ -51,6 +51,8 @@ struct DeviceState {
     hipStream_t side[3] = { nullptr, nullptr, nullptr };   // call_side_streams (created on first use)
     hipEvent_t side_done[3] = { nullptr, nullptr, nullptr };
     hipEvent_t side_fork = nullptr;
+    void* split_buf = nullptr;        // results of a split call's groups (split_call)
+    size_t split_bytes = 0;
 };
 static std::mutex g_dev_mu;
 static std::map<int, std::unique_ptr<DeviceState>> g_dev;
@@ -446,6 +448,295 @@ static int run_call(EvalCall& call, DeviceCtx* ctx) {
     }
 }
 
+// ---- light-cone splitting ---------------------------------------------------------------------
+// <0|U^+ P U|0> of a Pauli string P depends only on the gates inside the backward light cone of P's
+// qubits, and those gates touch the cone's qubits alone: the value is that of the circuit reduced to the
+// cone, on as many qubits as the cone has.  A call whose terms have small cones (a sum of local terms
+// behind a shallow circuit on a wide register: the variational eigensolver's energy) is therefore dealt
+// into groups of terms, each evaluated on its own compacted circuit -- cone qubits renumbered in ascending
+// order, gates outside the cone dropped, the parameters and input angles under their old numbers -- and
+// the groups' results are added into the caller's output.  X / Y factors are measured as Z behind H or
+// RZ(pi/2), H appended to the compacted circuit (RZ(a) = diag(e^{ia/2}, e^{-ia/2}): RZ(pi/2) is S^+ up
+// to a phase), so the terms of a group agree qubit by qubit on the basis.  Exact, like the pruning of
+// single gates.  Taken when the library chose the engine itself and the groups together cost less than
+// the whole register; VQA_NO_CONE_SPLIT=1 (or VQA_NO_CONE=1) switches it off.
+static int create_circuit(int engine_pref, int n_qubits, const vqa_op* ops, int n_ops, int n_theta, int n_input,
+                          vqa_circuit** out);
+static int run_call(EvalCall& call, DeviceCtx* ctx);
+
+struct SplitGroup {
+    uint64_t zs = 0, xs = 0;           // union of the terms' masks
+    uint64_t xb = 0, yb = 0, zb = 0;   // measurement basis by qubit
+    uint64_t qmask = 0;                // the cone's qubits
+    int live = 0;                      // parameters inside the cone
+    bool marg = false;                 // the call's marginal is measured here
+    std::vector<int> terms;            // indices into the call's term list
+    vqa_circuit* sub = nullptr;        // the compacted circuit
+    std::vector<std::unique_ptr<vqa_obs>> obs;   // Z-only observables on its qubits, one per observable of the call present
+    std::vector<const vqa_obs*> obs_ptr;
+    std::vector<int32_t> parent;       // ... and which observable of the call each one adds to
+};
+struct SplitPlan {
+    bool use = false;
+    std::vector<SplitGroup> groups;
+    ~SplitPlan() {
+        for (SplitGroup& g : groups)
+            if (g.sub) vqa_circuit_destroy(g.sub);
+    }
+};
+
+static int popcount64(uint64_t v) { return __builtin_popcountll(v); }
+
+// what a group costs, in amplitudes touched per gate layer: the register engine up to 14 qubits, the
+// streaming engine beyond (slower per amplitude, and a chain of launches per sample)
+static double split_cost(int nq, int live, bool sweep, double n_inst) {
+    const bool reg = nq <= kRegBits + kMaxThreadBits;
+    return ldexp(1.0, nq) * (sweep ? live + 1 : 1) * n_inst * (reg ? 1.0 : 8.0) + (reg ? 0x1p23 : 0x1p27);
+}
+
+static void split_walk(const vqa_circuit& c, uint64_t zs, uint64_t xs, uint64_t* qmask, int* live, std::vector<uint8_t>* gate_dead) {
+    std::vector<uint8_t> gd;
+    const std::vector<uint8_t> dead = dead_parameters(c, zs, xs, &gd);
+    uint64_t q = zs | xs;
+    for (int g = 0; g < c.n_ops; ++g)
+        if (!gd[g]) {
+            q |= (uint64_t)1 << c.ops[g].q0;
+            if (c.ops[g].q1 >= 0 && (c.ops[g].kind == VQA_GATE_CNOT || c.ops[g].kind == VQA_GATE_CZ)) q |= (uint64_t)1 << c.ops[g].q1;
+        }
+    int n = 0;
+    for (uint8_t d : dead) n += !d;
+    *qmask = q ? q : 1;   // (a call with identity terms only: one qubit, no gate)
+    *live = n;
+    if (gate_dead) gate_dead->swap(gd);
+}
+
+static uint64_t compact_mask(uint64_t m, uint64_t qmask) {
+    uint64_t out = 0;
+    int pos = 0;
+    for (int q = 0; q < 64; ++q)
+        if ((qmask >> q) & 1) {
+            if ((m >> q) & 1) out |= (uint64_t)1 << pos;
+            ++pos;
+        }
+    return out;
+}
+
+// The plan of a call's observables (cached on the circuit; the caller holds no lock).  Null: run the call whole.
+static SplitPlan* split_plan(vqa_circuit* c, const ObsPack& obs, int n_marg_bits, bool sweep, int64_t n_inst) {
+    if (!c->auto_engine || getenv("VQA_NO_CONE_SPLIT") || getenv("VQA_NO_CONE")) return nullptr;
+    if (obs.n_terms == 0 && n_marg_bits == 0) return nullptr;
+    int bucket = 0;
+    while (bucket < 16 && ((int64_t)1 << (bucket + 1)) <= n_inst) ++bucket;
+    std::vector<uint64_t> key = { (uint64_t)obs.n_obs, (uint64_t)n_marg_bits, (uint64_t)sweep, (uint64_t)bucket };
+    for (int o = 0; o < obs.n_obs; ++o)
+        for (int t = obs.off[o]; t < obs.off[o + 1]; ++t) {
+            uint64_t cb;
+            memcpy(&cb, &obs.coef[t], 8);
+            key.push_back((uint64_t)o); key.push_back(obs.z[t]); key.push_back(obs.x[t]); key.push_back(cb);
+        }
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        auto it = c->splits.find(key);
+        if (it != c->splits.end()) {
+            SplitPlan* sp = (SplitPlan*)it->second.get();
+            return sp->use ? sp : nullptr;
+        }
+    }
+    const double ninst = (double)((int64_t)1 << bucket);
+    auto plan = std::make_shared<SplitPlan>();
+    // the whole call
+    uint64_t zs_all = n_marg_bits > 0 ? (((uint64_t)1 << n_marg_bits) - 1) : 0, xs_all = 0;
+    for (int t = 0; t < obs.n_terms; ++t) { zs_all |= obs.z[t]; xs_all |= obs.x[t]; }
+    uint64_t q_all;
+    int live_all;
+    split_walk(*c, zs_all, xs_all, &q_all, &live_all, nullptr);
+    const double whole = split_cost(c->n_qubits, live_all, sweep, ninst);
+    // greedy grouping: a term joins the group whose cost it raises least, when that is less than a group of its own costs
+    std::vector<int> term_obs(obs.n_terms, 0);
+    for (int o = 0; o < obs.n_obs; ++o)
+        for (int t = obs.off[o]; t < obs.off[o + 1]; ++t) term_obs[t] = o;
+    std::vector<SplitGroup>& G = plan->groups;
+    auto group_cost = [&](const SplitGroup& g) { return split_cost(popcount64(g.qmask), g.live, sweep, ninst); };
+    if (n_marg_bits > 0) {
+        SplitGroup g;
+        g.marg = true;
+        g.zs = g.zb = ((uint64_t)1 << n_marg_bits) - 1;
+        split_walk(*c, g.zs, g.xs, &g.qmask, &g.live, nullptr);
+        G.push_back(std::move(g));
+    }
+    for (int t = 0; t < obs.n_terms; ++t) {
+        const uint64_t tx = obs.x[t] & ~obs.z[t], ty = obs.x[t] & obs.z[t], tz = obs.z[t] & ~obs.x[t];
+        uint64_t q1;
+        int l1;
+        split_walk(*c, obs.z[t], obs.x[t], &q1, &l1, nullptr);
+        const double alone = split_cost(popcount64(q1), l1, sweep, ninst);
+        int best = -1;
+        double best_delta = alone;
+        uint64_t best_q = 0;
+        int best_live = 0;
+        for (size_t k = 0; k < G.size(); ++k) {
+            const SplitGroup& g = G[k];
+            if ((tx & (g.yb | g.zb)) || (ty & (g.xb | g.zb)) || (tz & (g.xb | g.yb))) continue;
+            uint64_t qu;
+            int lu;
+            if ((q1 & ~g.qmask) == 0) { qu = g.qmask; lu = g.live; }   // (inside the group's cone already)
+            else split_walk(*c, g.zs | obs.z[t], g.xs | obs.x[t], &qu, &lu, nullptr);
+            const double delta = split_cost(popcount64(qu), lu, sweep, ninst) - group_cost(g);
+            if (delta < best_delta) { best = (int)k; best_delta = delta; best_q = qu; best_live = lu; }
+        }
+        if (best < 0) {
+            SplitGroup g;
+            g.qmask = q1;
+            g.live = l1;
+            G.push_back(std::move(g));
+            best = (int)G.size() - 1;
+        } else {
+            G[best].qmask = best_q;
+            G[best].live = best_live;
+        }
+        SplitGroup& g = G[best];
+        g.zs |= obs.z[t]; g.xs |= obs.x[t];
+        g.xb |= tx; g.yb |= ty; g.zb |= tz;
+        g.terms.push_back(t);
+    }
+    double total = 0.0;
+    for (const SplitGroup& g : G) total += group_cost(g);
+    plan->use = total < 0.7 * whole && G.size() <= 4096;
+    if (getenv("VQA_PLAN_DEBUG")) {
+        fprintf(stderr, "[vqa] light-cone split: %zu groups (qubits:", G.size());
+        for (size_t k = 0; k < G.size() && k < 64; ++k) fprintf(stderr, " %d", popcount64(G[k].qmask));
+        fprintf(stderr, "), cost %.3g against %.3g whole: %s\n", total, whole, plan->use ? "taken" : "not taken");
+    }
+    if (plan->use) {
+        for (SplitGroup& g : G) {
+            // the compacted circuit
+            std::vector<uint8_t> gate_dead;
+            split_walk(*c, g.zs, g.xs, &g.qmask, &g.live, &gate_dead);
+            int pos_of[64];
+            int nq = 0;
+            for (int q = 0; q < 64; ++q) pos_of[q] = ((g.qmask >> q) & 1) ? nq++ : -1;
+            std::vector<vqa_op> ops;
+            for (int i = 0; i < c->n_ops; ++i) {
+                if (gate_dead[i]) continue;
+                vqa_op op = c->ops[i];
+                op.q0 = pos_of[op.q0];
+                if (op.kind == VQA_GATE_CNOT || op.kind == VQA_GATE_CZ) op.q1 = pos_of[op.q1];
+                ops.push_back(op);
+            }
+            for (int q = 0; q < 64; ++q) {
+                const uint64_t b = (uint64_t)1 << q;
+                if (!((g.xb | g.yb) & b)) continue;
+                vqa_op op;
+                memset(&op, 0, sizeof(op));
+                op.q0 = pos_of[q];
+                op.q1 = -1;
+                op.src = VQA_SRC_CONST;
+                if (g.yb & b) {
+                    op.kind = VQA_GATE_RZ;
+                    op.coef = 1.0;
+                    op.offset = 1.5707963267948966;
+                    ops.push_back(op);
+                    op.coef = op.offset = 0.0;
+                }
+                op.kind = VQA_GATE_H;
+                ops.push_back(op);
+            }
+            if (create_circuit(0, nq, ops.data(), (int)ops.size(), c->n_theta, c->n_input, &g.sub) != VQA_OK) {
+                plan->use = false;
+                break;
+            }
+            // the group's observables: one per observable of the call that has terms here
+            for (int t : g.terms) {
+                const int o = term_obs[t];
+                size_t k = 0;
+                while (k < g.parent.size() && g.parent[k] != o) ++k;
+                if (k == g.parent.size()) {
+                    g.parent.push_back(o);
+                    g.obs.emplace_back(new vqa_obs());
+                    g.obs.back()->n_qubits = nq;
+                }
+                g.obs[k]->coef.push_back(obs.coef[t]);
+                g.obs[k]->z.push_back(compact_mask(obs.z[t] | obs.x[t], g.qmask));
+                g.obs[k]->x.push_back(0);
+            }
+            for (auto& o : g.obs) g.obs_ptr.push_back(o.get());
+            if ((int)g.obs.size() > kMaxObs) { plan->use = false; break; }
+        }
+    }
+    std::lock_guard<std::mutex> lk(c->mu);
+    auto it = c->splits.emplace(key, plan).first;
+    SplitPlan* sp = (SplitPlan*)it->second.get();
+    return sp->use ? sp : nullptr;
+}
+
+struct SplitMap {
+    int32_t parent[kMaxObs];
+};
+// out[row, parent[j]] += part[row, j]
+__global__ void k_split_add(const double* __restrict__ part, int n_part, double* __restrict__ out, int n_obs, SplitMap map,
+                            int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int64_t row = i / n_part;
+    const int j = (int)(i - row * n_part);
+    out[row * n_obs + map.parent[j]] += part[i];
+}
+
+// Runs a call group by group (the device is locked by the caller).
+static int split_call(const EvalCall& whole, SplitPlan& plan, DeviceState* ds) {
+    const int64_t E = whole.E;
+    if (E <= 0) return VQA_OK;
+    const int n_obs = whole.obs.n_obs;
+    size_t part_max = 0;
+    for (const SplitGroup& g : plan.groups) part_max = std::max(part_max, g.obs.size());
+    const size_t need = (size_t)E * part_max * sizeof(double);
+    VQA_HIP(hipSetDevice(whole.device));
+    if (ds->split_bytes < need) {
+        if (ds->split_buf) {
+            VQA_HIP(hipDeviceSynchronize());
+            VQA_HIP(hipFree(ds->split_buf));
+            ds->split_buf = nullptr;
+            ds->split_bytes = 0;
+        }
+        const size_t want = (need + 65535) & ~(size_t)65535;
+        hipError_t e = hipMalloc(&ds->split_buf, want);
+        if (e != hipSuccess) VQA_FAIL(VQA_ENOMEM, "hipMalloc of %zu bytes for the groups' results failed: %s", want, hipGetErrorString(e));
+        ds->split_bytes = want;
+    }
+    double* part = (double*)ds->split_buf;
+    if (n_obs > 0) VQA_HIP(hipMemsetAsync(whole.d_out_expect, 0, (size_t)E * n_obs * sizeof(double), whole.stream));
+    for (SplitGroup& g : plan.groups) {
+        if (g.obs.empty() && !g.marg) continue;
+        EvalCall call = whole;
+        call.c = g.sub;
+        int rc = pack_obs(g.sub, g.obs_ptr.data(), (int)g.obs_ptr.size(), &call.obs);
+        if (rc) return rc;
+        DeviceCtx* ctx;
+        rc = circuit_device_ctx(g.sub, whole.device, &ctx);
+        if (rc) return rc;
+        call.d_ops = ctx->d_ops;
+        call.n_marg_bits = g.marg ? whole.n_marg_bits : 0;
+        call.d_out_marginal = g.marg ? whole.d_out_marginal : nullptr;
+        call.cone = cone_of(g.sub, call.obs, call.n_marg_bits);
+        call.d_out_expect = part;
+        const int n_part = (int)g.obs.size();
+        // (a caller's parameter subset leaves the other rows unwritten)
+        if (whole.param_mask && n_part > 0) VQA_HIP(hipMemsetAsync(part, 0, (size_t)E * n_part * sizeof(double), whole.stream));
+        rc = run_call(call, ctx);
+        if (rc) return rc;
+        if (n_part > 0) {
+            SplitMap map;
+            memset(&map, 0, sizeof(map));
+            for (int j = 0; j < n_part; ++j) map.parent[j] = g.parent[j];
+            const int64_t total = E * n_part;
+            hipLaunchKernelGGL(k_split_add, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, whole.stream, part, n_part,
+                               whole.d_out_expect, n_obs, map, total);
+            VQA_HIP(hipGetLastError());
+        }
+    }
+    return VQA_OK;
+}
+
 static int check_common(vqa_circuit* c, int device, const double* theta, const double* input, int B,
                         int n_obs, int n_marg_bits, const double* out_e, const double* out_m) {
     if (!c) VQA_FAIL(VQA_EINVAL, "circuit handle is NULL");
@@ -522,6 +813,14 @@ int vqa_set_engine(int engine) {
 
 int vqa_circuit_create(int n_qubits, const vqa_op* ops, int n_ops, int n_theta, int n_input,
                        vqa_circuit** out) {
+    return create_circuit(g_engine, n_qubits, ops, n_ops, n_theta, n_input, out);
+}
+
+}  // extern "C"
+
+namespace vqa {
+static int create_circuit(int engine_pref, int n_qubits, const vqa_op* ops, int n_ops, int n_theta, int n_input,
+                          vqa_circuit** out) {
     if (!out) VQA_FAIL(VQA_EINVAL, "out is NULL");
     if (n_qubits < 1 || n_qubits > 30) VQA_FAIL(VQA_EINVAL, "n_qubits must be in [1, 30] (got %d)", n_qubits);
     if (n_ops < 0 || (n_ops > 0 && !ops)) VQA_FAIL(VQA_EINVAL, "ops is NULL or n_ops < 0");
@@ -541,7 +840,7 @@ int vqa_circuit_create(int n_qubits, const vqa_op* ops, int n_ops, int n_theta, 
                 VQA_FAIL(VQA_EINVAL, "op %d: input index %d out of range [0, %d)", g, op.idx, n_input);
         }
     }
-    int engine = g_engine;
+    int engine = engine_pref;
     std::shared_ptr<RegProgram> reg;
     if ((engine == 0 && n_qubits >= kRegBits && n_qubits <= kRegBits + kMaxThreadBits) || engine == 2) {
         reg = std::make_shared<RegProgram>();
@@ -567,11 +866,14 @@ int vqa_circuit_create(int n_qubits, const vqa_op* ops, int n_ops, int n_theta, 
     c->n_theta = n_theta;
     c->n_input = n_input;
     c->engine = engine;
-    c->auto_engine = g_engine == 0;
+    c->auto_engine = engine_pref == 0;
     c->ops.assign(ops, ops + n_ops);
     *out = c;
     return VQA_OK;
 }
+}  // namespace vqa
+
+extern "C" {
 
 int vqa_circuit_engine(const vqa_circuit* c) {
     if (!c) VQA_FAIL(VQA_EINVAL, "circuit handle is NULL");
@@ -659,6 +961,9 @@ static int eval_dev_common(vqa_circuit* c, int device, void* stream, const doubl
     call.param_mask = param_mask;
     call.d_out_expect = d_out_e;
     call.d_out_marginal = d_out_m;
+    if (SplitPlan* sp = split_plan(c, call.obs, n_marg_bits, spec.psr && call.n_sweep > 0,
+                                   spec.psr && call.n_sweep > 0 ? call.n_sweep : E))
+        return split_call(call, *sp, guard.ds);
     return run_call(call, ctx);
 }
 

@@ -157,6 +157,7 @@ struct vqa_circuit {
     int hbm_tiles = 0;                     // engine 3: the build whose plans this circuit holds (11 or 12; 0: not chosen yet)
     std::map<uint64_t, std::shared_ptr<void>> hbm_hplans;   // engine 3: Hadamard layers used to measure X-type terms, by qubit mask
     std::map<std::pair<uint64_t, uint64_t>, std::shared_ptr<vqa::ConeInfo>> cones;   // by (Z-type, general) measured qubits
+    std::map<std::vector<uint64_t>, std::shared_ptr<void>> splits;   // light-cone splits of a call's terms, by the terms (vqa_abi.hip)
     std::mutex mu;
     std::map<int, vqa::DeviceCtx> dev;
 };
