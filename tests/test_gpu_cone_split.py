@@ -194,3 +194,93 @@ def test_twenty_eight_qubit_split_against_whole_register():
     finally:
         _lib.lib().vqa_set_engine(0)
     assert np.abs(got[0, [0, 7, 302]] - ref).max() < TOL
+
+
+def local_random_circuit(n, layers, seed, shared=False):
+    """Layers of random one-qubit gates (trainable, input, constant; every kind) and random gates between ring
+    neighbours: backward light cones stay a few qubits wide."""
+    rng = np.random.default_rng(seed)
+    c = LearningCircuit(n)
+    n_par = 0
+    for _ in range(layers):
+        for q in range(n):
+            k = int(rng.integers(8))
+            ax = "XYZ"[int(rng.integers(3))]
+            if k < 3:
+                if shared and n_par > 2 and rng.random() < 0.2:
+                    getattr(c, f"add_parametric_R{ax}_gate")(q, 0.0, share_with=int(rng.integers(n_par)),
+                                                              share_with_coef=float(rng.uniform(-2, 2)))
+                else:
+                    getattr(c, f"add_parametric_R{ax}_gate")(q, float(rng.uniform(0, 6.28)))
+                    n_par += 1
+            elif k == 3:
+                getattr(c, f"add_input_R{ax}_gate")(q, lambda x, q=q: x[q % len(x)] * (1 + 0.03 * q))
+            elif k == 4:
+                getattr(c, f"add_R{ax}_gate")(q, float(rng.uniform(-3, 3)))
+            elif k == 5:
+                c.add_H_gate(q)
+            elif k == 6:
+                getattr(c, f"add_{ax}_gate")(q)
+        for q in range(int(rng.integers(2)), n, 2):
+            q1 = (q + 1) % n
+            r = rng.random()
+            if r < 0.4:
+                c.add_CZ_gate(q, q1)
+            elif r < 0.6:
+                c.add_CNOT_gate(q, q1)
+            elif r < 0.7:
+                c.add_CNOT_gate(q1, q)
+            elif r < 0.8:
+                c.add_CNOT_gate(q, q1)
+                c.add_input_RZ_gate(q1, lambda x, q=q: x[q % len(x)] * 0.7)
+                c.add_CNOT_gate(q, q1)
+    return c
+
+
+def local_random_observables(n, seed, n_obs=6):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n_obs):
+        o = Observable(n)
+        for _ in range(int(rng.integers(1, 4))):
+            q = int(rng.integers(n))
+            s = " ".join(f"{'XYZ'[int(rng.integers(3))]} {(q + d) % n}" for d in range(int(rng.integers(1, 4))))
+            o.add_operator(float(rng.uniform(-1, 1)), s)
+        out.append(o)
+    return out
+
+
+def state_pass_counters(reset=False):
+    import ctypes as C
+
+    rw, ro = C.c_int64(0), C.c_int64(0)
+    _lib.check(_lib.lib().vqa_state_pass_counters(C.byref(rw), C.byref(ro), int(reset)))
+    return rw.value + ro.value
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_split_random_local_circuits(seed):
+    """Random shallow circuits of every gate kind on 15 to 19 qubits, random local Pauli strings: sweeps, with
+    every parameter driving one rotation (seeds 0-3) or some of them shared between gates (4, 5: the groups'
+    circuits then run the sweep as an explicit list), and explicit lists, against the oracle on the whole
+    register.  The streaming engine must not have run: the groups fit the register engine."""
+    n = 15 + seed % 5
+    c = local_random_circuit(n, 2 + seed % 2, 100 + seed, shared=seed >= 4)
+    rng = np.random.default_rng(seed)
+    theta = rng.uniform(-np.pi, np.pi, c.n_theta)
+    x = rng.uniform(0, np.pi, (3, 4))
+    obs = local_random_observables(n, 200 + seed)
+    state_pass_counters(reset=True)
+    got, gm = c.psr_full(theta, c.input_angles(x), sel=np.array([2, 0], np.int32), obs_list=obs, n_marg_bits=seed % 3)
+    assert state_pass_counters() == 0
+    for r, j in enumerate((2, 0)):
+        want, wm = oracle_sweep(c, theta, x, obs, n_marg_bits=seed % 3, j=j)
+        assert np.abs(got[r] - want).max() < TOL
+        if seed % 3:
+            assert np.abs(gm[r] - wm).max() < TOL
+    si = np.array([1, 1, 0, 2], np.int32)
+    sp = np.array([-1, 0, c.n_theta - 1, c.n_theta // 2], np.int32)
+    sv = np.array([0.0, 0.3, -1.1, 0.5 * np.pi])
+    want, _ = cpu_oracle.eval_batch(c, theta, c.input_angles(x), si, sp, sv, obs_list=obs_tuples(obs), n_threads=4)
+    e, _ = c.eval_batch(theta, c.input_angles(x), si, sp, sv, obs_list=obs)
+    assert np.abs(e - want).max() < TOL
