@@ -2890,7 +2890,10 @@ int reg_engine_sweep(const EvalCall& call, const void* d_prog, const RegProgram&
     // which runs the unshifted circuit for its own checkpoints first (a single circuit, the VQE
     // case, would otherwise keep one workgroup busy and the rest of the GPU idle).
     const int64_t n_runs_max = std::max(P.hdr.n_runs, 1);
-    const int split = (int)std::max<int64_t>(1, std::min<int64_t>(slots / n_samples, n_runs_max));
+    // (no more slices than the list has entries: workgroups without work would still hold a CU's LDS while they
+    // start and leave, which keeps launches of other streams off the GPU)
+    const int64_t n_entries = std::max<int64_t>(1, (int64_t)(two_runs ? n_live / 2 : n_live));
+    const int split = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(slots / n_samples, n_runs_max), n_entries));
     const int grid = (int)std::min<int64_t>((int64_t)n_samples * split, slots);
     const size_t ck_bytes = (size_t)grid * (P.hdr.n_ddesc + 1) * ((size_t)16 << P.hdr.n);
     const size_t rec_bytes = (size_t)grid * std::max(P.hdr.n_runs, 1) * sizeof(RunRec);

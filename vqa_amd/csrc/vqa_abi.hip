@@ -53,6 +53,8 @@ struct DeviceState {
     hipEvent_t side_fork = nullptr;
     void* split_buf = nullptr;        // results of a split call's groups (split_call)
     size_t split_bytes = 0;
+    void* ws_side[3] = { nullptr, nullptr, nullptr };   // workspaces of the groups that run on the side streams (slice i: side[i - 1] only)
+    size_t ws_side_bytes[3] = { 0, 0, 0 };
 };
 static std::mutex g_dev_mu;
 static std::map<int, std::unique_ptr<DeviceState>> g_dev;
@@ -162,7 +164,34 @@ int hbm_engine_statevector(const EvalCall& call, double* d_out_state) {
     return small_tiles(call) ? hbm_engine_statevector_t11(call, d_out_state) : hbm_engine_statevector_t12(call, d_out_state);
 }
 
+// The workspace of a group of a split call that runs on side stream `slice - 1`: that stream is its only user, so
+// the stream's own order is all the ordering it needs.
+static int workspace_slice(int device, int slice, size_t bytes, void** out) {
+    DeviceState* ds;
+    int rc = device_state(device, &ds);
+    if (rc) return rc;
+    std::lock_guard<std::recursive_mutex> lk(*ds->call_mu);
+    VQA_HIP(hipSetDevice(device));
+    void*& ws = ds->ws_side[slice - 1];
+    size_t& have = ds->ws_side_bytes[slice - 1];
+    if (have < bytes) {
+        if (ws) {
+            VQA_HIP(hipDeviceSynchronize());
+            VQA_HIP(hipFree(ws));
+            ws = nullptr;
+            have = 0;
+        }
+        const size_t want = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+        hipError_t e = hipMalloc(&ws, want);
+        if (e != hipSuccess) VQA_FAIL(VQA_ENOMEM, "hipMalloc of %zu workspace bytes failed: %s", want, hipGetErrorString(e));
+        have = want;
+    }
+    *out = ws;
+    return VQA_OK;
+}
+
 int call_workspace(const EvalCall& call, size_t bytes, void** out) {
+    if (!call.fixed && call.ws_slice > 0) return workspace_slice(call.device, call.ws_slice, bytes, out);
     if (!call.fixed) return workspace_get(call.device, call.stream, bytes, out);
     FixedScratch& f = *call.fixed;
     const size_t at = (f.used + 255) & ~(size_t)255;
@@ -236,10 +265,13 @@ int upload_by_value(hipStream_t stream, void* d_dst, const void* src, size_t byt
 }
 
 int call_upload(const EvalCall& call, void* d_dst, const void* src, size_t bytes) {
-    if (!call.fixed) {
-        if (bytes) VQA_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, call.stream));
+    // (a table of one chunk travels as a kernel argument either way: queuing a copy from pageable memory costs the
+    // host some 50 us, a launch a tenth of it)
+    if (!call.fixed && bytes > sizeof(UploadChunk)) {
+        VQA_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, call.stream));
         return VQA_OK;
     }
+    if (bytes == 0) return VQA_OK;
     return upload_by_value(call.stream, d_dst, src, bytes);
 }
 
@@ -479,6 +511,7 @@ struct SplitGroup {
 struct SplitPlan {
     bool use = false;
     std::vector<SplitGroup> groups;
+    std::vector<int32_t> gather;   // tables of k_split_gather: obs_off[n_obs + 1], then the entries (built on first use)
     ~SplitPlan() {
         for (SplitGroup& g : groups)
             if (g.sub) vqa_circuit_destroy(g.sub);
@@ -669,27 +702,56 @@ static SplitPlan* split_plan(vqa_circuit* c, const ObsPack& obs, int n_marg_bits
     return sp->use ? sp : nullptr;
 }
 
-struct SplitMap {
-    int32_t parent[kMaxObs];
-};
-// out[row, parent[j]] += part[row, j]
-__global__ void k_split_add(const double* __restrict__ part, int n_part, double* __restrict__ out, int n_obs, SplitMap map,
-                            int64_t total) {
+// out[row, o] = sum of the groups' columns that belong to observable o, in the plan's fixed order.
+// part: the groups' blocks one after the other, block g = [E, width_g]; entries: (first column of the group's
+// block, its width, the column inside it), obs_off[o] .. obs_off[o + 1] those of observable o.
+__global__ void k_split_gather(const double* __restrict__ part, int64_t E, const int32_t* __restrict__ obs_off,
+                               const int32_t* __restrict__ entries, double* __restrict__ out, int n_obs) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int64_t row = i / n_part;
-    const int j = (int)(i - row * n_part);
-    out[row * n_obs + map.parent[j]] += part[i];
+    if (i >= E * n_obs) return;
+    const int64_t row = i / n_obs;
+    const int o = (int)(i - row * n_obs);
+    double acc = 0.0;
+    for (int k = obs_off[o]; k < obs_off[o + 1]; ++k) {
+        const int32_t first = entries[3 * k], width = entries[3 * k + 1], col = entries[3 * k + 2];
+        acc += part[E * first + row * width + col];
+    }
+    out[i] = acc;
 }
 
-// Runs a call group by group (the device is locked by the caller).
+// Runs a call group by group (the device is locked by the caller).  Every group writes its [E, width] block of
+// the part buffer; one kernel on the call's stream adds the blocks into the caller's output at the end.  A call of
+// few instances leaves most of the GPU idle per group (one sample's runs on a few dozen workgroups), so its
+// groups go round-robin to the call's stream and the library's side streams, each with a workspace of its own.
 static int split_call(const EvalCall& whole, SplitPlan& plan, DeviceState* ds) {
     const int64_t E = whole.E;
     if (E <= 0) return VQA_OK;
     const int n_obs = whole.obs.n_obs;
-    size_t part_max = 0;
-    for (const SplitGroup& g : plan.groups) part_max = std::max(part_max, g.obs.size());
-    const size_t need = (size_t)E * part_max * sizeof(double);
+    // the gather tables (built once per plan) and the blocks' first columns
+    std::vector<int32_t> first(plan.groups.size(), 0);
+    int n_cols = 0;
+    for (size_t g = 0; g < plan.groups.size(); ++g) {
+        first[g] = n_cols;
+        n_cols += (int)plan.groups[g].obs.size();
+    }
+    {
+        std::lock_guard<std::mutex> lk(whole.c->mu);
+        if (plan.gather.empty()) {
+            std::vector<int32_t> off(n_obs + 1, 0), ent;
+            for (int o = 0; o < n_obs; ++o) {
+                for (size_t g = 0; g < plan.groups.size(); ++g)
+                    for (size_t j = 0; j < plan.groups[g].parent.size(); ++j)
+                        if (plan.groups[g].parent[j] == o) {
+                            ent.push_back(first[g]); ent.push_back((int32_t)plan.groups[g].obs.size()); ent.push_back((int32_t)j);
+                        }
+                off[o + 1] = (int32_t)(ent.size() / 3);
+            }
+            plan.gather = off;
+            plan.gather.insert(plan.gather.end(), ent.begin(), ent.end());
+        }
+    }
+    const size_t tab_bytes = (plan.gather.size() * sizeof(int32_t) + 255) & ~(size_t)255;
+    const size_t need = tab_bytes + (size_t)E * n_cols * sizeof(double);
     VQA_HIP(hipSetDevice(whole.device));
     if (ds->split_bytes < need) {
         if (ds->split_buf) {
@@ -703,36 +765,72 @@ static int split_call(const EvalCall& whole, SplitPlan& plan, DeviceState* ds) {
         if (e != hipSuccess) VQA_FAIL(VQA_ENOMEM, "hipMalloc of %zu bytes for the groups' results failed: %s", want, hipGetErrorString(e));
         ds->split_bytes = want;
     }
-    double* part = (double*)ds->split_buf;
-    if (n_obs > 0) VQA_HIP(hipMemsetAsync(whole.d_out_expect, 0, (size_t)E * n_obs * sizeof(double), whole.stream));
-    for (SplitGroup& g : plan.groups) {
+    // (the part buffer is shared by all calls on the device, like the workspace: taking the workspace orders this
+    // call's stream behind the previous user's)
+    void* unused;
+    int rc = workspace_get(whole.device, whole.stream, 1, &unused);
+    if (rc) return rc;
+    int32_t* d_tab = (int32_t*)ds->split_buf;
+    double* part = (double*)((char*)ds->split_buf + tab_bytes);
+    if (n_obs > 0) {
+        rc = plan.gather.size() * sizeof(int32_t) <= 3072
+                 ? upload_by_value(whole.stream, d_tab, plan.gather.data(), plan.gather.size() * sizeof(int32_t))
+                 : (hipMemcpyAsync(d_tab, plan.gather.data(), plan.gather.size() * sizeof(int32_t), hipMemcpyHostToDevice,
+                                   whole.stream) == hipSuccess ? VQA_OK : VQA_EHIP);
+        if (rc) VQA_FAIL(rc, "upload of the gather tables failed");
+    }
+    // (a caller's parameter subset leaves the other rows of the blocks unwritten)
+    if (whole.param_mask && n_cols > 0) VQA_HIP(hipMemsetAsync(part, 0, (size_t)E * n_cols * sizeof(double), whole.stream));
+    // side streams: when a group cannot fill the GPU and none of the groups runs on the streaming engine (which
+    // spreads its own work over the same streams)
+    hipStream_t side[3];
+    hipEvent_t done[3], fork;
+    int n_side = 0;
+    const bool few = whole.spec.psr && whole.n_sweep > 0 ? whole.n_sweep <= 64 : E <= 4096;
+    bool small_engines = true;
+    for (const SplitGroup& g : plan.groups) small_engines &= g.sub && g.sub->engine != 3 && g.sub->engine != 4;
+    if (few && small_engines && plan.groups.size() >= 2 && !getenv("VQA_SPLIT_ONE_STREAM")) {
+        n_side = call_side_streams(whole, (int)std::min<size_t>(3, plan.groups.size() - 1), side, done, &fork);
+        if (n_side > 0) {
+            VQA_HIP(hipEventRecord(fork, whole.stream));
+            for (int i = 0; i < n_side; ++i) VQA_HIP(hipStreamWaitEvent(side[i], fork, 0));
+        }
+    }
+    int turn = 0;
+    rc = VQA_OK;
+    for (size_t gi = 0; gi < plan.groups.size() && rc == VQA_OK; ++gi) {
+        SplitGroup& g = plan.groups[gi];
         if (g.obs.empty() && !g.marg) continue;
         EvalCall call = whole;
         call.c = g.sub;
-        int rc = pack_obs(g.sub, g.obs_ptr.data(), (int)g.obs_ptr.size(), &call.obs);
-        if (rc) return rc;
+        call.ws_slice = turn % (n_side + 1);
+        call.stream = call.ws_slice == 0 ? whole.stream : side[call.ws_slice - 1];
+        ++turn;
+        rc = pack_obs(g.sub, g.obs_ptr.data(), (int)g.obs_ptr.size(), &call.obs);
+        if (rc) break;
         DeviceCtx* ctx;
         rc = circuit_device_ctx(g.sub, whole.device, &ctx);
-        if (rc) return rc;
+        if (rc) break;
         call.d_ops = ctx->d_ops;
         call.n_marg_bits = g.marg ? whole.n_marg_bits : 0;
         call.d_out_marginal = g.marg ? whole.d_out_marginal : nullptr;
         call.cone = cone_of(g.sub, call.obs, call.n_marg_bits);
-        call.d_out_expect = part;
-        const int n_part = (int)g.obs.size();
-        // (a caller's parameter subset leaves the other rows unwritten)
-        if (whole.param_mask && n_part > 0) VQA_HIP(hipMemsetAsync(part, 0, (size_t)E * n_part * sizeof(double), whole.stream));
+        call.d_out_expect = part + (size_t)E * first[gi];
         rc = run_call(call, ctx);
-        if (rc) return rc;
-        if (n_part > 0) {
-            SplitMap map;
-            memset(&map, 0, sizeof(map));
-            for (int j = 0; j < n_part; ++j) map.parent[j] = g.parent[j];
-            const int64_t total = E * n_part;
-            hipLaunchKernelGGL(k_split_add, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, whole.stream, part, n_part,
-                               whole.d_out_expect, n_obs, map, total);
-            VQA_HIP(hipGetLastError());
+    }
+    // the call's stream waits for the side streams whatever happened above
+    for (int i = 0; i < n_side; ++i) {
+        if (hipEventRecord(done[i], side[i]) != hipSuccess || hipStreamWaitEvent(whole.stream, done[i], 0) != hipSuccess) {
+            (void)hipDeviceSynchronize();
+            if (rc == VQA_OK) VQA_FAIL(VQA_EHIP, "joining the side streams of a split call failed");
         }
+    }
+    if (rc) return rc;
+    if (n_obs > 0) {
+        const int64_t total = E * n_obs;
+        hipLaunchKernelGGL(k_split_gather, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, whole.stream, part, E, d_tab,
+                           d_tab + (n_obs + 1), whole.d_out_expect, n_obs);
+        VQA_HIP(hipGetLastError());
     }
     return VQA_OK;
 }

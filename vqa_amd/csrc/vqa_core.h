@@ -181,6 +181,7 @@ struct EvalCall {  // one batched evaluation, all pointers on the device
     double* d_out_expect;
     double* d_out_marginal;
     struct FixedScratch* fixed = nullptr;  // non-null: the call must not allocate; its working memory is this region
+    int ws_slice = 0;  // > 0: a group of a split call on side stream ws_slice - 1, with that stream's own workspace
 };
 
 // A fixed region of device memory that serves as a call's working memory (the allocation-free
