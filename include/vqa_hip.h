@@ -191,6 +191,18 @@ int vqa_eval_batch_dev(vqa_circuit* c, int device, void* stream,
  * spread them over a few more streams of the library's own: they start behind
  * an event on the caller's stream, and the caller's stream waits for them
  * before the call returns, so the caller orders against `stream` alone.
+ *
+ * Light cones.  <0|U^+ P U|0> of a Pauli string P depends only on the gates inside the backward
+ * light cone of P's qubits, and those gates touch the cone's qubits alone.  When the library chose
+ * the engine itself (vqa_set_engine(0)) and the cones of a call's terms are narrower than the
+ * register -- local terms behind a shallow circuit on many qubits, the energy of a variational
+ * eigensolver -- vqa_eval_batch[_dev], vqa_psr_full[_dev] and vqa_psr_params_dev deal the terms
+ * into groups and evaluate every group on the circuit reduced to its cone (cone qubits renumbered,
+ * gates outside dropped, X / Y factors measured as Z behind appended basis gates; parameters and
+ * input angles keep their numbers), then add the groups' results into the caller's output in a
+ * fixed order.  The values are those of the whole register up to rounding.  A call of few
+ * instances runs its groups on the caller's stream and on streams of the library's own, ordered
+ * against `stream` as described above.  VQA_NO_CONE_SPLIT=1 in the environment switches it off.
  */
 int vqa_psr_full(vqa_circuit* c, int device,
                  const double* theta, const double* input_angles, int B,
