@@ -271,6 +271,20 @@ int vqa_dead_parameters(vqa_circuit* c, const vqa_obs* const* obs, int n_obs,
                         int n_marg_bits, uint8_t* out_dead);
 
 /*
+ * How vqa_eval_batch[_dev] / vqa_psr_full[_dev] / vqa_psr_params_dev would deal the Pauli terms of these
+ * observables (and the marginal) into light-cone groups, each evaluated on the circuit reduced to the
+ * group's backward light cone (see vqa_psr_full): returns the number of groups, 0 when the call runs on
+ * the whole register, or a negative VQA_E* code; the groups' register sizes go to
+ * out_qubits[0 .. min(groups, max_out)) when out_qubits is not NULL.  sweep != 0: n_instances samples
+ * of a full parameter-shift sweep, else n_instances circuit evaluations of an explicit list (the choice
+ * weighs the groups' launches against the work, which grows with the instances).  Host only, no GPU
+ * work; the plan is cached on the circuit and reused by the calls.  No counterpart in the reference,
+ * which runs every circuit on the whole register (vqa/QNN/myQNNs_base.py:692-704).
+ */
+int vqa_light_cone_groups(vqa_circuit* c, const vqa_obs* const* obs, int n_obs, int n_marg_bits,
+                          int sweep, int64_t n_instances, int32_t* out_qubits, int max_out);
+
+/*
  * Shot sampling.  For each of E rows draws counts[e, 0..n_outcomes) ~ Multinomial(shots[e],
  * probs[e, :]) (row-major; a row of probs is used as given, its last entry takes what the
  * others leave; negative or NaN entries count as 0).  With probs = the marginal of the

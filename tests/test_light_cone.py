@@ -70,3 +70,58 @@ def test_other_ansaetze(builder):
     rng = np.random.default_rng(3)
     o = Observable(6); o.add_operator(1.0, "Z 2"); o.add_operator(0.5, "X 3")
     check(c, [o], 1, rng.uniform(0, np.pi, (2, 6)), rng.uniform(-3, 3, c.n_theta))
+
+
+# ---- light-cone groups (host-side planning, no GPU) ---------------------------------------------
+def _ising_terms(n):
+    from vqa_amd import Observable
+
+    out = []
+    for i in range(n):
+        for s in (f"Z {i} Z {(i + 1) % n}", f"X {i}"):
+            o = Observable(n)
+            o.add_operator(1.0, s)
+            out.append(o)
+    return out
+
+
+def test_light_cone_groups_of_the_ising_ring():
+    """28 qubits, RY layers with six CZ rings between them: the cone of Z_i Z_{i+1} is 14 qubits wide, that of
+    X_i 13; the ZZ terms run on their own, the X terms two to a group (their basis differs from the ZZ terms'
+    on the shared qubit): 42 groups of 14 qubits.  A forced engine keeps the whole register."""
+    from vqa_amd import LearningCircuit, _lib
+    from vqa_amd.qml_utils import create_ry_cz_ansatz
+
+    n = 28
+    c = create_ry_cz_ansatz(n, 6, seed=4, circuit_cls=LearningCircuit)
+    g = c.light_cone_groups(_ising_terms(n))
+    assert len(g) == 42 and set(g.tolist()) == {14}
+    # depth 2: cones of 5 and 6 qubits; a handful of wider groups is cheaper than 56 launches
+    c2 = create_ry_cz_ansatz(n, 2, seed=4, circuit_cls=LearningCircuit)
+    g2 = c2.light_cone_groups(_ising_terms(n))
+    assert 0 < len(g2) < 42 and g2.max() <= 14
+    # many samples: the work outweighs the launches, narrower groups
+    g3 = c2.light_cone_groups(_ising_terms(n), n_instances=4096)
+    assert len(g3) >= len(g2) and g3.max() <= g2.max()
+    _lib.check(_lib.lib().vqa_set_engine(3))
+    try:
+        c3 = create_ry_cz_ansatz(n, 6, seed=4, circuit_cls=LearningCircuit)
+        assert len(c3.light_cone_groups(_ising_terms(n))) == 0
+    finally:
+        _lib.lib().vqa_set_engine(0)
+
+
+def test_light_cone_groups_keep_a_full_cone_whole():
+    """The 20-qubit IBM-HEA circuit of depth 8 with <Z0>: behind eight CZ rings and the two ring feature maps
+    the cone is the whole register -- nothing to split.  At depth 1 the cone is 7 qubits wide."""
+    from vqa_amd import LearningCircuit, Observable
+    from vqa_amd.qml_utils import create_ibm_HEA_ansatz
+
+    z0 = Observable(20)
+    z0.add_operator(1.0, "Z 0")
+    deep = create_ibm_HEA_ansatz(20, 8, seed=0, circuit_cls=LearningCircuit)
+    assert len(deep.light_cone_groups([z0], n_instances=1024)) == 0
+    assert len(deep.light_cone_groups([z0], n_marg_bits=2, n_instances=1024)) == 0
+    shallow = create_ibm_HEA_ansatz(20, 1, seed=0, circuit_cls=LearningCircuit)
+    g = shallow.light_cone_groups([z0], n_instances=64)
+    assert g.tolist() == [7]

@@ -22,7 +22,7 @@ EXPORTS = (
     "vqa_eval_batch", "vqa_eval_batch_dev", "vqa_psr_full", "vqa_psr_full_dev",
     "vqa_statevector", "vqa_sample_counts", "vqa_sample_counts_dev", "vqa_dead_parameters", "vqa_psr_params_dev",
     "vqa_psr_full_noalloc_dev", "vqa_mse_stats_workspace", "vqa_mse_stats_dev", "vqa_mse_stats_shard_dev", "vqa_irandom_stats_dev", "vqa_class_grad_dev", "vqa_class_stats_dev", "vqa_sample_counts_shard_dev",
-    "vqa_state_pass_counters",
+    "vqa_state_pass_counters", "vqa_light_cone_groups",
 )
 
 
@@ -83,6 +83,7 @@ def lib():
     L.vqa_sample_counts_dev.argtypes = [C.c_int, vp, dp, C.c_int, ip, C.c_int64, C.c_uint64, C.c_uint64, ip]
     L.vqa_sample_counts_shard_dev.argtypes = L.vqa_sample_counts_dev.argtypes + [C.c_int64]
     L.vqa_state_pass_counters.argtypes = [C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int]
+    L.vqa_light_cone_groups.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int64, vp, C.c_int]
     for name in EXPORTS:
         fn = getattr(L, name)
         if name not in ("vqa_last_error", "vqa_mse_stats_workspace"):

@@ -357,6 +357,20 @@ static std::vector<uint8_t> dead_parameters(const vqa_circuit& c, uint64_t zsupp
             break;
         }
         case VQA_GATE_CNOT: {   // q0 = target, q1 = control
+            // CNOT - RZ(target) - CNOT is the diagonal gate exp(i a/2 Z_c Z_t) (the ZZ feature maps): it commutes
+            // with Z-type factors on both qubits and hands a Z-type factor to the partner of a general one, like CZ
+            // (gate by gate the first CNOT would spread a Z-type factor from its target to its control for good)
+            if (g >= 2 && c.ops[g - 1].kind == VQA_GATE_RZ && c.ops[g - 1].q0 == op.q0 && c.ops[g - 2].kind == VQA_GATE_CNOT &&
+                c.ops[g - 2].q0 == op.q0 && c.ops[g - 2].q1 == op.q1) {
+                const uint64_t f = full;
+                live = (f & (b0 | b1)) != 0;
+                if ((f & b0) && !(f & b1)) zonly |= b1;
+                if ((f & b1) && !(f & b0)) zonly |= b0;
+                (*gate_dead)[g] = (*gate_dead)[g - 1] = (*gate_dead)[g - 2] = live ? 0 : 1;
+                if (live && c.ops[g - 1].src == VQA_SRC_THETA) dead[c.ops[g - 1].idx] = 0;
+                g -= 2;
+                continue;
+            }
             const uint64_t f = full, z = zonly;
             live = ((f | z) & b0) != 0 || (f & b1) != 0;
             if (((f | z) & b0) && !(f & b1)) zonly |= b1;          // Z_t -> Z_c Z_t
@@ -1265,6 +1279,25 @@ int vqa_psr_full_noalloc_dev(vqa_circuit* c, int device, void* stream, const dou
     if (reg_engine_can_sweep(*c->reg) && reg_engine_can_sweep(*prog)) return reg_engine_sweep(call, d_prog, *prog, n_sel);
     if (reg_engine_can_group(*prog)) return reg_engine_group(call, d_prog, *prog, n_sel);
     return reg_engine_run(call, d_prog, *prog);
+}
+
+int vqa_light_cone_groups(vqa_circuit* c, const vqa_obs* const* obs, int n_obs, int n_marg_bits, int sweep,
+                          int64_t n_instances, int32_t* out_qubits, int max_out) {
+    if (!c) VQA_FAIL(VQA_EINVAL, "circuit handle is NULL");
+    if (n_marg_bits < 0 || n_marg_bits > c->n_qubits) VQA_FAIL(VQA_EINVAL, "n_marg_bits must be in [0, n_qubits] (got %d)", n_marg_bits);
+    if (n_instances < 1) VQA_FAIL(VQA_EINVAL, "n_instances must be >= 1");
+    ObsPack pack;
+    int rc = pack_obs(c, obs, n_obs, &pack);
+    if (rc) return rc;
+    SplitPlan* sp = split_plan(c, pack, n_marg_bits, sweep != 0, n_instances);
+    if (!sp) return 0;
+    int n = 0;
+    for (const SplitGroup& g : sp->groups) {
+        if (g.obs.empty() && !g.marg) continue;
+        if (out_qubits && n < max_out) out_qubits[n] = g.sub ? g.sub->n_qubits : 0;
+        ++n;
+    }
+    return n;
 }
 
 int vqa_dead_parameters(vqa_circuit* c, const vqa_obs* const* obs, int n_obs, int n_marg_bits, uint8_t* out_dead) {

@@ -294,6 +294,16 @@ class LearningCircuit(GateList):
                                                   _lib.nptr(out)))
         return out[:self.n_theta].astype(bool)
 
+    def light_cone_groups(self, obs_list: Sequence[Observable] = (), n_marg_bits: int = 0, sweep: bool = True,
+                          n_instances: int = 1) -> np.ndarray:
+        """Register sizes of the light-cone groups the library would deal the terms of ``obs_list`` into for a
+        sweep of ``n_instances`` samples (``sweep=False``: an explicit list of that many evaluations); an empty
+        array when the call runs on the whole register.  Host only."""
+        out = np.zeros(4096, np.int32)
+        n = _lib.check(_lib.lib().vqa_light_cone_groups(self.handle(), self._obs_array(obs_list), len(obs_list), n_marg_bits,
+                                                        int(sweep), int(n_instances), _lib.nptr(out), len(out)))
+        return out[:min(n, len(out))].copy()
+
     def psr_full(self, theta, inputs, sel=None, n_sel: Optional[int] = None,
                  shift: float = 0.5 * np.pi, obs_list: Sequence[Observable] = (), n_marg_bits: int = 0,
                  stream=None, out_expect=None, out_marginal=None, params=None):
