@@ -284,3 +284,30 @@ def test_split_random_local_circuits(seed):
     want, _ = cpu_oracle.eval_batch(c, theta, c.input_angles(x), si, sp, sv, obs_list=obs_tuples(obs), n_threads=4)
     e, _ = c.eval_batch(theta, c.input_angles(x), si, sp, sv, obs_list=obs)
     assert np.abs(e - want).max() < TOL
+
+
+def test_split_groups_on_the_streaming_engine():
+    """21 qubits behind seven CZ rings: cones of 15 and 16 qubits, beyond the register engine -- the groups'
+    reduced circuits run on the tiled passes themselves (one after the other on the caller's stream).  Against
+    the whole register, and the unshifted and two shifted rows against the oracle."""
+    n, depth = 21, 7
+    c = create_ry_cz_ansatz(n, depth, seed=11)
+    theta = np.random.default_rng(11).uniform(-np.pi, np.pi, c.n_theta)
+    x = np.zeros((1, 1))
+    obs = []
+    for s in ("Z 0 Z 1", "X 0", "Z 10 Z 11", "X 20", "Y 5", "Z 20 Z 0"):
+        o = Observable(n)
+        o.add_operator(1.0, s)
+        obs.append(o)
+    widths = c.light_cone_groups(obs)
+    assert len(widths) >= 3 and widths.min() >= 15
+    got, _ = c.psr_full(theta, c.input_angles(x), n_sel=1, obs_list=obs)
+    with env(VQA_NO_CONE_SPLIT=1):
+        c2 = create_ry_cz_ansatz(n, depth, seed=11)
+        whole, _ = c2.psr_full(theta, c2.input_angles(x), n_sel=1, obs_list=obs)
+    assert np.abs(got - whole).max() < TOL
+    si, sp, sv = sweep_instances(c.n_theta)
+    pick = np.array([0, 2 * 80 + 1, 2 * 167 + 2])
+    want, _ = cpu_oracle.eval_batch(c, theta, c.input_angles(x), si[pick], sp[pick], sv[pick], obs_list=obs_tuples(obs),
+                                    n_threads=3)
+    assert np.abs(got[0, pick] - want).max() < TOL
