@@ -2799,6 +2799,14 @@ int reg_engine_sweep(const EvalCall& call, const void* d_prog, const RegProgram&
         if (!cone.reg_built) {
             for (int r = 0; r < P.hdr.n_runs; ++r)
                 if (!cone.dead[P.runs[r].param]) cone.reg_live_runs.push_back(r);
+            // by the checkpoint a run starts from (late resumption: the diagonal stage behind its U-stage), so that
+            // runs that load the same image follow one another (pair_up below; the image is warm in L2 for the next)
+            auto stage_of = [&](int32_t r) {
+                const ParamInfo& pi = P.params[P.runs[r].param];
+                return (P.runs[r].variant == 0 && pi.late_mask != 0) ? pi.late_diag : pi.resume_diag;
+            };
+            std::stable_sort(cone.reg_live_runs.begin(), cone.reg_live_runs.end(),
+                             [&](int32_t x, int32_t y) { return stage_of(x) < stage_of(y); });
             cone.reg_built = true;
         }
     }

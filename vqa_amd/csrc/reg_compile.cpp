@@ -6,6 +6,7 @@
 // (vqa/QNN/QML_utils.py:33-164): H layers, ZZ feature maps written as
 // CNOT-RZ-CNOT sandwiches, RX/RY/RZ layers and CZ rings; any list of the
 // supported gate kinds compiles.
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -121,6 +122,27 @@ std::vector<Stage> normal_form(const std::vector<vqa_op>& ops) {
     // change Z-basis probabilities, which is all this engine measures
     if (!st.empty() && !st.front().isU) st.erase(st.begin());
     if (!st.empty() && !st.back().isU) st.pop_back();
+    // A trainable RZ at the end of a qubit's run commutes with the diagonal stage behind it: it opens the qubit's
+    // run of the NEXT U-stage instead (RZ RY RX | CZ ring | RZ RY RX  ->  RY RX | CZ ring | RZ RY RX RZ).  The
+    // fused 2x2s stay one per qubit and stage; a parameter-shift run of that parameter then resumes one diagonal
+    // stage and one U-stage later (a third of the hardware-efficient ansatz' parameters).  VQA_NO_RZ_FORWARD=1: as listed.
+    if (!getenv("VQA_NO_RZ_FORWARD")) {
+        for (size_t i = 0; i + 2 < st.size(); ++i) {
+            if (!st[i].isU || st[i + 1].isU || !st[i + 2].isU) continue;
+            for (auto it = st[i].g.begin(); it != st[i].g.end();) {
+                std::vector<ElemGate>& run = it->second;
+                auto nx = st[i + 2].g.find(it->first);
+                size_t moved = 0;
+                while (nx != st[i + 2].g.end() && run.size() > 1 && run.back().kind == VQA_GATE_RZ && run.back().src == VQA_SRC_THETA) {
+                    nx->second.insert(nx->second.begin(), run.back());
+                    run.pop_back();
+                    ++moved;
+                }
+                (void)moved;
+                ++it;
+            }
+        }
+    }
     return st;
 }
 
