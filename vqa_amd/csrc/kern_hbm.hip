@@ -1218,27 +1218,57 @@ static TilePlan plan_tiles(int n, const std::vector<vqa_op>& ops, const std::vec
     std::vector<PG> pg;
     std::vector<std::vector<TileGate>> runs;   // the 1-qubit gates of a run, in order
     std::vector<int> open(n, -1);              // the run a qubit's next 1-qubit gate joins (index into pg), -1: none
+    // A trainable RZ at the end of a qubit's run commutes with the CZ / ZZ gates behind it: it is carried over them and
+    // opens the qubit's next run, so that its parameter's state branches off a layer later in a parameter-shift sweep
+    // (the register engine does the same, reg_compile.cpp).  VQA_NO_RZ_FORWARD=1: as listed.
+    std::vector<std::vector<TileGate>> carry(n);
+    const bool forward = !getenv("VQA_NO_RZ_FORWARD");
+    auto close_run = [&](int q) {              // a CZ / ZZ gate on q: the run ends, its trailing trainable RZs travel on
+        if (open[q] >= 0 && forward) {
+            std::vector<TileGate>& run = runs[pg[open[q]].g];
+            size_t keep = run.size();
+            while (keep > 1 && run[keep - 1].kind == VQA_GATE_RZ && ops[run[keep - 1].g].src == VQA_SRC_THETA) --keep;
+            carry[q].insert(carry[q].begin(), run.begin() + keep, run.end());
+            run.resize(keep);
+        }
+        open[q] = -1;
+    };
+    auto open_run = [&](int q) {               // the run the next 1-qubit gate on q joins, the carried gates first
+        if (open[q] < 0) {
+            open[q] = (int)pg.size();
+            pg.push_back(PG{ kGateU, q, -1, (int)runs.size() });
+            runs.emplace_back(carry[q]);
+            carry[q].clear();
+        }
+    };
     for (size_t i = 0; i < ops.size(); ++i) {
         const vqa_op& op = ops[i];
         if (is_dead(i)) continue;
         if (op.kind == VQA_GATE_CNOT && i + 2 < ops.size() && ops[i + 1].kind == VQA_GATE_RZ && ops[i + 1].q0 == op.q0 &&
             ops[i + 2].kind == VQA_GATE_CNOT && ops[i + 2].q0 == op.q0 && ops[i + 2].q1 == op.q1 &&
             !is_dead(i + 1) && !is_dead(i + 2)) {
+            close_run(op.q0);
+            close_run(op.q1);
             pg.push_back(PG{ kGateZZ, op.q0, op.q1, (int)i + 1 });
-            open[op.q0] = open[op.q1] = -1;
             i += 2;
-        } else if (op.kind == VQA_GATE_CNOT || op.kind == VQA_GATE_CZ) {
+        } else if (op.kind == VQA_GATE_CZ) {
+            close_run(op.q0);
+            close_run(op.q1);
             pg.push_back(PG{ op.kind, op.q0, op.q1, (int)i });
-            open[op.q0] = open[op.q1] = -1;
-        } else {
-            if (open[op.q0] < 0) {
-                open[op.q0] = (int)pg.size();
-                pg.push_back(PG{ kGateU, op.q0, -1, (int)runs.size() });
-                runs.emplace_back();
+        } else if (op.kind == VQA_GATE_CNOT) {
+            // (not diagonal: what was carried so far is applied in front of it, as a run of its own)
+            for (int q : { op.q0, op.q1 }) {
+                if (!carry[q].empty()) { open[q] = -1; open_run(q); }
+                open[q] = -1;
             }
+            pg.push_back(PG{ op.kind, op.q0, op.q1, (int)i });
+        } else {
+            open_run(op.q0);
             runs[pg[open[op.q0]].g].push_back(TileGate{ op.kind, -1, -1, (int)i });
         }
     }
+    for (int q = 0; q < n; ++q)
+        if (!carry[q].empty()) { open[q] = -1; open_run(q); }
     // runs of diagonal gates only stay single diagonal gates
     {
         std::vector<PG> out;
