@@ -417,7 +417,7 @@ int vqa_statevector(vqa_circuit* c, int device,
 /*
  * Engine selection for circuits created afterwards on this thread's process:
  * 0 = automatic, 1 = LDS gate-by-gate engine (n <= 13), 2 = register-blocked
- * fused engine (4 <= n <= 13), 3 = HBM streaming engine (any n; tiled passes from
+ * fused engine (4 <= n <= 14), 3 = HBM streaming engine (any n; tiled passes from
  * 13 qubits on), 4 = HBM streaming engine with one sweep per gate.  For tests
  * and benchmarks that compare engines; not part of the reference interface.
  */
