@@ -100,7 +100,10 @@ struct RegArgs {
     double* out_expect;
     double* out_marginal;
     double2* ckpt;     // sweep: per-workgroup checkpoint area
-    unsigned* next;    // sweep: work counter (zero at launch); workgroups take samples from it
+    unsigned* next;    // sweep: work counter; workgroups take samples from it (tickets count from next_base)
+    unsigned next_base;   // ... what the counter holds when the launch starts (unsigned arithmetic, the counter may wrap)
+    const int32_t* dead;  // sweep kernels: parameters outside the light cone of the call's observables; the workgroup that runs
+    int n_dead;           //   slice 0 of a sample writes their rows (copies of the unshifted row)
     RunRec* recs;      // sweep: per-workgroup run records
     const int32_t* live;  // sweep: the runs to execute, ascending (the others' outputs are filled in by the caller)
     int n_live;
@@ -1167,6 +1170,42 @@ __device__ __forceinline__ double measure(const double2 (&amp)[kRegAmps], const 
     return 1.0 / inv_norm;
 }
 
+// The kernel's argument block once more, for values that are needed once per sample: what is read through this
+// pointer is loaded behind the call, not held in scalar registers around the run loop (the sweep kernels sit at
+// the limit of those, and one more live value there costs 3 % of the headline rate in spills).
+__device__ __forceinline__ const VQA_CAS RegArgs* late_args() {
+    const VQA_CAS void* p = (const VQA_CAS void*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return (const VQA_CAS RegArgs*)p;
+}
+
+// Rows 2i+1 and 2i+2 of the sample whose row 0 is instance row0, for the parameters i of the call's dead list:
+// copies of the unshifted values in basev (what a separate pass over the output did before: one launch less per
+// sweep).
+__device__ __forceinline__ void fill_dead_params(const double* basev, int64_t row0, bool valid, int tid, int nthr) {
+    const VQA_CAS RegArgs* la = late_args();
+    const int n_dead = la->n_dead;
+    if (n_dead <= 0) return;
+    const double nanv = __longlong_as_double(0x7ff8000000000000LL);
+    const int nmb = la->n_marg_bits, no = la->obs.n_obs, nq = no + (nmb > 0 ? (1 << nmb) : 0);
+    const int32_t* dead = la->dead;
+    double* oe = la->out_expect;
+    double* om = la->out_marginal;
+    __syncthreads();   // the unshifted values are thread 0's
+    for (int idx = tid; idx < n_dead * nq; idx += nthr) {
+        const int d = idx / nq, q = idx - d * nq;
+        const int64_t e1 = row0 + 2 * (int64_t)dead[d] + 1;
+        const double v = valid ? basev[q] : nanv;
+        if (q < no) {
+            oe[e1 * no + q] = v;
+            oe[(e1 + 1) * no + q] = v;
+        } else {
+            om[(e1 << nmb) + (q - no)] = v;
+            om[((e1 + 1) << nmb) + (q - no)] = v;
+        }
+    }
+}
+
 // Both shifted values of one parameter from ONE extra state.  With psi the
 // unshifted final state and phi the final state of the circuit that has the
 // parameter's generator inserted in front of its rotation, the states at
@@ -1657,7 +1696,10 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : BLOCK == 512 ? 2 : BLOCK
 #endif
     for (;;) {
         __syncthreads();
-        if (tid == 0) s_next = atomicAdd(a.next, 1u);
+        if (tid == 0) {
+            const VQA_CAS RegArgs* la = late_args();
+            s_next = atomicAdd(la->next, 1u) - la->next_base;
+        }
         __syncthreads();
         // a work item is a sample, or (few samples) one of the a.split slices of a sample's run list
         const int64_t item = s_next;
@@ -1800,6 +1842,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : BLOCK == 512 ? 2 : BLOCK
             // hand the fetched record over (read by everybody after the barrier on top)
             if (tid < 8 && ri + 1 < NL) pz[tid] = nx;
         }
+        // the rows of the parameters outside the light cone (behind the runs: the loop above stays as it was)
+        if (slice == 0) fill_dead_params(basev, j * K, valid, tid, BLOCK);
     }
 }
 
@@ -2199,7 +2243,10 @@ __global__ __launch_bounds__(BLOCK, VQA_PSR2_WAVES) void k_reg_psr2(RegArgs a) {
     __shared__ unsigned s_next2;
     for (;;) {
         __syncthreads();
-        if (tid == 0) s_next2 = atomicAdd(a.next, 1u);
+        if (tid == 0) {
+            const VQA_CAS RegArgs* la = late_args();
+            s_next2 = atomicAdd(la->next, 1u) - la->next_base;
+        }
         __syncthreads();
         const int64_t item = s_next2;
         const int64_t j = item / a.split;
@@ -2320,6 +2367,8 @@ __global__ __launch_bounds__(BLOCK, VQA_PSR2_WAVES) void k_reg_psr2(RegArgs a) {
             }
             if (tid < 16 && it + 1 < NI) pz[tid] = nx;
         }
+        // the rows of the parameters outside the light cone (behind the runs: the loop above stays as it was)
+        if (slice == 0) fill_dead_params(basev, j * K, valid, tid, BLOCK);
     }
 }
 
@@ -2733,6 +2782,9 @@ static RegArgs make_args(const EvalCall& call, const void* d_prog) {
     a.out_marginal = call.d_out_marginal;
     a.ckpt = nullptr;
     a.next = nullptr;
+    a.next_base = 0;
+    a.dead = nullptr;
+    a.n_dead = 0;
     a.recs = nullptr;
     a.live = nullptr;
     a.n_live = 0;
@@ -2911,18 +2963,27 @@ int reg_engine_sweep(const EvalCall& call, const void* d_prog, const RegProgram&
     void* ws = nullptr;
     rc = call_workspace(call, 256 + live_bytes + ck_bytes + rec_bytes, &ws);
     if (rc) return rc;
-    a.next = (unsigned*)ws;
-    int32_t* d_live = (int32_t*)((char*)ws + 256);
-    int32_t* d_dead = (int32_t*)((char*)ws + 256 + live_part);
     a.ckpt = (double2*)((char*)ws + 256 + live_bytes);
     a.recs = (RunRec*)((char*)ws + 256 + live_bytes + ck_bytes);
-    a.live = d_live;
     a.n_live = (int)(two_runs ? n_live / 2 : n_live);
     a.split = (int)std::max<size_t>(1, std::min<size_t>((size_t)split, (size_t)a.n_live));
-    VQA_HIP(hipMemsetAsync(a.next, 0, 256, call.stream));
-    // (the lists live as long as the circuit: the asynchronous copies may read them after this returns)
-    if (n_live && (rc = call_upload(call, d_live, live_runs.data(), n_live * sizeof(int32_t)))) return rc;
-    if (n_dead && (rc = call_upload(call, d_dead, dead_list.data(), (size_t)n_dead * sizeof(int32_t)))) return rc;
+    // The lists: a cone's default lists stay on the device; a caller's parameter subset and a call that must not
+    // allocate upload theirs into the workspace (the cached host lists live as long as the circuit: the
+    // asynchronous copies may read them after this returns).
+    const int32_t *d_live = nullptr, *d_dead = nullptr;
+    if (!call.param_mask && !call.fixed) {
+        if ((rc = cone_lists_dev(call, two_runs ? 1 : 0, live_runs, dead_list, &d_live, &d_dead))) return rc;
+    } else {
+        int32_t* w_live = (int32_t*)((char*)ws + 256);
+        int32_t* w_dead = (int32_t*)((char*)ws + 256 + live_part);
+        if (n_live && (rc = call_upload(call, w_live, live_runs.data(), n_live * sizeof(int32_t)))) return rc;
+        if (n_dead && (rc = call_upload(call, w_dead, dead_list.data(), (size_t)n_dead * sizeof(int32_t)))) return rc;
+        d_live = w_live;
+        d_dead = w_dead;
+    }
+    a.live = d_live;
+    a.dead = d_dead;
+    a.n_dead = n_dead;
     const void* fn = two_runs ? (P.hdr.block == 64 ? (const void*)k_reg_psr2<64>
                                : P.hdr.block == 128 ? (const void*)k_reg_psr2<128>
                                : P.hdr.block == 256 ? (const void*)k_reg_psr2<256>
@@ -2933,6 +2994,16 @@ int reg_engine_sweep(const EvalCall& call, const void* d_prog, const RegProgram&
                    : P.hdr.block == 512 ? (const void*)k_reg_psr<512>
                                         : (const void*)k_reg_psr<1024>;
     VQA_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_psr));
+    // The work counter: the device's own, which is never cleared (the launch is told where it stands), or, for a
+    // call that must not allocate, the head of its region, cleared here.
+    const unsigned draws = (unsigned)((int64_t)n_samples * a.split + grid);
+    a.next = call_ticket_counter(call, draws, &a.next_base);
+    const bool own_counter = a.next == nullptr;
+    if (own_counter) {
+        a.next = (unsigned*)ws;
+        a.next_base = 0;
+        VQA_HIP(hipMemsetAsync(a.next, 0, 256, call.stream));
+    }
     if (two_runs) {
         switch (P.hdr.block) {
         case 64: hipLaunchKernelGGL(k_reg_psr2<64>, dim3(grid), dim3(64), lds_psr, call.stream, a); break;
@@ -2948,14 +3019,9 @@ int reg_engine_sweep(const EvalCall& call, const void* d_prog, const RegProgram&
     case 512: hipLaunchKernelGGL(k_reg_psr<512>, dim3(grid), dim3(512), lds_psr, call.stream, a); break;
     default: hipLaunchKernelGGL(k_reg_psr<1024>, dim3(grid), dim3(1024), lds_psr, call.stream, a); break;
     }
-    VQA_HIP(hipGetLastError());
-    if (n_dead) {
-        const int K = 2 * call.c->n_theta + 1;
-        rc = fill_dead_rows(call.stream, call.d_out_expect, n_samples, K, call.obs.n_obs, d_dead, n_dead);
-        if (rc) return rc;
-        if (call.n_marg_bits > 0)
-            rc = fill_dead_rows(call.stream, call.d_out_marginal, n_samples, K, 1 << call.n_marg_bits, d_dead, n_dead);
-        if (rc) return rc;
+    if (hipGetLastError() != hipSuccess) {
+        if (!own_counter) call_ticket_reset(call);   // (the counter will not advance as the host assumed)
+        VQA_FAIL(VQA_EHIP, "launch of the sweep kernel failed");
     }
     if (call.param_mask) VQA_HIP(hipStreamSynchronize(call.stream));
     return VQA_OK;
@@ -3087,13 +3153,21 @@ int reg_engine_group(const EvalCall& call, const void* d_prog, const RegProgram&
     void* ws = nullptr;
     rc = call_workspace(call, live_part + dead_part + ck_bytes + rec_bytes + 1024, &ws);
     if (rc) return rc;
-    int32_t* d_live = (int32_t*)ws;
-    int32_t* d_dead = (int32_t*)((char*)ws + live_part);
+    const int32_t *d_live = nullptr, *d_dead = nullptr;
     a.ckpt = (double2*)((char*)ws + ((live_part + dead_part + 255) & ~(size_t)255));
     a.recs = (RunRec*)((char*)a.ckpt + ((ck_bytes + 255) & ~(size_t)255));
-    // (the cached lists live as long as the circuit; a per-call list is waited for below)
-    if (n_live && (rc = call_upload(call, d_live, live_k.data(), n_live * sizeof(int32_t)))) return rc;
-    if (n_dead && (rc = call_upload(call, d_dead, dead_list.data(), n_dead * sizeof(int32_t)))) return rc;
+    // a cone's default lists stay on the device; a caller's parameter subset and a call that must not allocate
+    // upload theirs (the cached host lists live as long as the circuit; a per-call list is waited for below)
+    if (!call.param_mask && !call.fixed) {
+        if ((rc = cone_lists_dev(call, late ? 3 : 2, live_k, dead_list, &d_live, &d_dead))) return rc;
+    } else {
+        int32_t* w_live = (int32_t*)ws;
+        int32_t* w_dead = (int32_t*)((char*)ws + live_part);
+        if (n_live && (rc = call_upload(call, w_live, live_k.data(), n_live * sizeof(int32_t)))) return rc;
+        if (n_dead && (rc = call_upload(call, w_dead, dead_list.data(), n_dead * sizeof(int32_t)))) return rc;
+        d_live = w_live;
+        d_dead = w_dead;
+    }
     a.live = d_live;
     a.n_live = (int)n_live;
     a.need_psi = live_k[0] >= 0;

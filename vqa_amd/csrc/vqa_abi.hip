@@ -51,10 +51,13 @@ struct DeviceState {
     hipStream_t side[3] = { nullptr, nullptr, nullptr };   // call_side_streams (created on first use)
     hipEvent_t side_done[3] = { nullptr, nullptr, nullptr };
     hipEvent_t side_fork = nullptr;
+    hipEvent_t own_done = nullptr;    // the library's own stream handed out as a side stream (call_side_streams)
     void* split_buf = nullptr;        // results of a split call's groups (split_call)
     size_t split_bytes = 0;
     void* ws_side[3] = { nullptr, nullptr, nullptr };   // workspaces of the groups that run on the side streams (slice i: side[i - 1] only)
     size_t ws_side_bytes[3] = { 0, 0, 0 };
+    unsigned* tickets = nullptr;      // call_ticket_counter: one counter per workspace slice, 256 bytes apart, never cleared
+    unsigned ticket_base[4] = { 0, 0, 0, 0 };   // what the counters will hold when everything queued so far has run
 };
 static std::mutex g_dev_mu;
 static std::map<int, std::unique_ptr<DeviceState>> g_dev;
@@ -211,8 +214,17 @@ int call_side_streams(const EvalCall& call, int want, hipStream_t* streams, hipE
     if (hipSetDevice(call.device) != hipSuccess) return 0;
     if (!ds->side_fork && hipEventCreateWithFlags(&ds->side_fork, hipEventDisableTiming) != hipSuccess) return 0;
     int got = 0;
-    for (; got < std::min(want, 3); ++got) {
-        if (!ds->side[got]) {
+    want = std::min(want, 3);
+    // The library's own stream first, unless the call runs on it: it exists anyway and holds a hardware queue (a
+    // process gets four; with it left out the third side stream shared a queue with the second -- kernel trace of a
+    // 28-qubit gradient's groups: two streams on one queue, a third of the launches waiting for their turn).
+    if (ds->stream != call.stream && (ds->own_done || hipEventCreateWithFlags(&ds->own_done, hipEventDisableTiming) == hipSuccess)) {
+        streams[got] = ds->stream;
+        done[got] = ds->own_done;
+        ++got;
+    }
+    for (int k = 0; got < want && k < 3; ++k, ++got) {
+        if (!ds->side[k]) {
             hipStream_t st = nullptr;
             hipEvent_t ev = nullptr;
             if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) break;
@@ -220,14 +232,69 @@ int call_side_streams(const EvalCall& call, int want, hipStream_t* streams, hipE
                 (void)hipStreamDestroy(st);
                 break;
             }
-            ds->side[got] = st;
-            ds->side_done[got] = ev;
+            ds->side[k] = st;
+            ds->side_done[k] = ev;
         }
-        streams[got] = ds->side[got];
-        done[got] = ds->side_done[got];
+        streams[got] = ds->side[k];
+        done[got] = ds->side_done[k];
     }
     *fork = ds->side_fork;
     return got;
+}
+
+unsigned* call_ticket_counter(const EvalCall& call, unsigned draws, unsigned* base) {
+    if (call.fixed || call.ws_slice < 0 || call.ws_slice > 3) return nullptr;
+    DeviceState* ds;
+    if (device_state(call.device, &ds) != VQA_OK) return nullptr;
+    std::lock_guard<std::recursive_mutex> lk(*ds->call_mu);
+    if (!ds->tickets) {
+        if (hipSetDevice(call.device) != hipSuccess) return nullptr;
+        void* p = nullptr;
+        if (hipMalloc(&p, 4 * 256) != hipSuccess) return nullptr;
+        if (hipMemset(p, 0, 4 * 256) != hipSuccess) {
+            (void)hipFree(p);
+            return nullptr;
+        }
+        ds->tickets = (unsigned*)p;
+    }
+    *base = ds->ticket_base[call.ws_slice];
+    ds->ticket_base[call.ws_slice] += draws;   // (unsigned arithmetic on both sides: the counters may wrap)
+    return ds->tickets + 64 * call.ws_slice;
+}
+
+void call_ticket_reset(const EvalCall& call) {
+    DeviceState* ds;
+    if (device_state(call.device, &ds) != VQA_OK) return;
+    std::lock_guard<std::recursive_mutex> lk(*ds->call_mu);
+    if (!ds->tickets) return;
+    (void)hipDeviceSynchronize();
+    (void)hipMemset(ds->tickets, 0, 4 * 256);
+    for (unsigned& b : ds->ticket_base) b = 0;
+}
+
+int cone_lists_dev(const EvalCall& call, int kind, const std::vector<int32_t>& live, const std::vector<int32_t>& dead,
+                   const int32_t** d_live, const int32_t** d_dead) {
+    ConeInfo& cone = *call.cone;
+    std::lock_guard<std::mutex> lk(call.c->mu);
+    const size_t live_part = (live.size() * sizeof(int32_t) + 15) & ~(size_t)15;
+    auto it = cone.list_dev.find({ call.device, kind });
+    if (it == cone.list_dev.end()) {
+        VQA_HIP(hipSetDevice(call.device));
+        void* d = nullptr;
+        hipError_t e = hipMalloc(&d, std::max<size_t>(live_part + dead.size() * sizeof(int32_t), 16));
+        if (e != hipSuccess) VQA_FAIL(VQA_ENOMEM, "hipMalloc of a sweep's run list failed: %s", hipGetErrorString(e));
+        hipError_t e1 = live.empty() ? hipSuccess : hipMemcpy(d, live.data(), live.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+        hipError_t e2 = dead.empty() ? hipSuccess
+                                     : hipMemcpy((char*)d + live_part, dead.data(), dead.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+        if (e1 != hipSuccess || e2 != hipSuccess) {
+            (void)hipFree(d);
+            VQA_FAIL(VQA_EHIP, "upload of a sweep's run list failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+        }
+        it = cone.list_dev.emplace(std::make_pair(call.device, kind), d).first;
+    }
+    *d_live = (const int32_t*)it->second;
+    *d_dead = (const int32_t*)((const char*)it->second + live_part);
+    return VQA_OK;
 }
 
 size_t call_workspace_room(const EvalCall& call) {
@@ -999,11 +1066,16 @@ int vqa_circuit_destroy(vqa_circuit* c) {
         if (kv.second.d_ops) (void)hipFree(kv.second.d_ops);
         if (kv.second.reg_prog) (void)hipFree(kv.second.reg_prog);
     }
-    for (auto& kv : c->cones)
+    for (auto& kv : c->cones) {
         for (auto& dv : kv.second->reg_dev) {
             (void)hipSetDevice(dv.first);
             (void)hipFree(dv.second);
         }
+        for (auto& dv : kv.second->list_dev) {
+            (void)hipSetDevice(dv.first.first);
+            (void)hipFree(dv.second);
+        }
+    }
     delete c;
     return VQA_OK;
 }

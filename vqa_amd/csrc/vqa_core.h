@@ -141,6 +141,9 @@ struct ConeInfo {
     std::vector<int32_t> group_live_k;       // engine 2, small circuits: runs of the live parameters, pair runs first
     bool group_late_built = false;
     std::vector<int32_t> group_late_k;       // engine 2, grouped sweeps with late resumption: one run per live parameter, by U-stage (empty: not available)
+    // engine 2: device copies of a sweep's default run list and dead list, [runs, padded to 16 bytes | dead parameters],
+    // by (device, kind of list); uploaded when first used, freed with the circuit (cone_lists_dev)
+    std::map<std::pair<int, int>, void*> list_dev;
     bool hbm_built = false;
     std::vector<int32_t> hbm_ord, hbm_ord_pass, hbm_ord_sweep, hbm_unused;   // engine 3: the sweep plan's lists without the dead
     std::vector<double> hbm_coef;
@@ -257,6 +260,19 @@ int call_upload(const EvalCall& call, void* d_dst, const void* src, size_t bytes
 // the second form on its own: the source has been read when the function returns, whatever memory it is
 // in (a function-local table that must not outlive the call).  Same alignment and room as above.
 int upload_by_value(hipStream_t stream, void* d_dst, const void* src, size_t bytes);
+// Engine 2's sweeps read their run list and their dead list from the device.  The default lists of a cone (no caller's
+// parameter subset) are uploaded once per device and kept: *d_live / *d_dead point into that copy.  kind tells the
+// lists of the different sweep kernels apart (0: one run per workgroup, 1: items of two runs, 2: grouped sweeps,
+// 3: grouped sweeps with late resumption).  Not for calls that must not allocate.
+int cone_lists_dev(const EvalCall& call, int kind, const std::vector<int32_t>& live, const std::vector<int32_t>& dead,
+                   const int32_t** d_live, const int32_t** d_dead);
+// A work counter on the call's device that is never cleared: a sweep kernel's workgroups draw tickets from it with
+// atomic increments and subtract *base, the count before this launch; `draws` is what the launch will add (every
+// workgroup draws until a ticket lies past the end: items + workgroups), which the host adds to its own copy here.
+// One counter per workspace slice, whose users the device runs in the order they were queued.  Null for a call that
+// must not allocate (it clears a counter in its own region).  call_ticket_reset: after a launch that failed.
+unsigned* call_ticket_counter(const EvalCall& call, unsigned draws, unsigned* base);
+void call_ticket_reset(const EvalCall& call);
 // Up to three more streams of the library's own on the call's device, for a call that spreads independent
 // work over several hardware queues, with an event each and one event to start them from.  The call makes
 // them wait for *fork (recorded on its own stream) before their first kernel and its own stream wait for
