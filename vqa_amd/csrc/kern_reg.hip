@@ -2750,6 +2750,8 @@ __global__ __launch_bounds__(64, VQA_GROUP_WAVES) void k_reg_group_late(RegArgs 
                 const double nrm = measure(amp, a, pp, cx, red, parity, j * K, sl == 0, valid, sl == 0 ? basev : nullptr);
                 if (tid == 0) basev[79] = nrm;
                 __syncthreads();
+                // (the workgroup that runs a sample's first chunk also writes the rows of the parameters outside the light cone)
+                if (ch == 0) fill_dead_params(basev, j * K, valid, tid, BLOCK);
             }
             if (pass == 1 && live)
                 measure_pair(amp, 0u, basev[79], (const double2*)srec, basev, a, pp, cx, red, parity, j * K + kout, valid, psi);
@@ -3171,13 +3173,17 @@ int reg_engine_group(const EvalCall& call, const void* d_prog, const RegProgram&
     a.live = d_live;
     a.n_live = (int)n_live;
     a.need_psi = live_k[0] >= 0;
+    if (late) {   // (the late form writes the dead parameters' rows itself)
+        a.dead = d_dead;
+        a.n_dead = (int)n_dead;
+    }
     const void* fn = !late ? (const void*)k_reg_group : gck ? (const void*)k_reg_group_late<true> : (const void*)k_reg_group_late<false>;
     VQA_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (!late) hipLaunchKernelGGL(k_reg_group, dim3(grid), dim3(64), lds, call.stream, a);
     else if (gck) hipLaunchKernelGGL(k_reg_group_late<true>, dim3(grid), dim3(64), lds, call.stream, a);
     else hipLaunchKernelGGL(k_reg_group_late<false>, dim3(grid), dim3(64), lds, call.stream, a);
     VQA_HIP(hipGetLastError());
-    if (n_dead) {
+    if (n_dead && !late) {
         const int K = 2 * call.c->n_theta + 1;
         rc = fill_dead_rows(call.stream, call.d_out_expect, n_samples, K, call.obs.n_obs, d_dead, (int)n_dead);
         if (rc) return rc;
