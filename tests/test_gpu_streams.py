@@ -74,3 +74,44 @@ def test_sweeps_from_two_threads():
     for t in threads:
         t.join(timeout=120)
     assert not errors, errors
+
+
+def test_mixed_sweeps_share_a_work_counter_that_is_never_cleared():
+    """The sweep kernels of the register engine draw their work from a per-device counter that the library never
+    clears: every launch is told where the counter stands, and the host adds what the launch will draw.  A long mix
+    of sweeps of different circuits, sample counts (one sample: the run list is cut into slices), sample selections,
+    parameter subsets and streams must leave every result equal to the one the same call gives on its own."""
+    import torch
+
+    jobs = [problem(12, 3, 40, 11), problem(10, 4, 70, 12), problem(13, 2, 12, 13), problem(11, 3, 33, 14)]
+    full = []
+    for c, th, x, obs in jobs:
+        e, m = c.psr_full(th, x, obs_list=obs, n_marg_bits=1)
+        torch.cuda.synchronize()
+        full.append((e.cpu().numpy(), m.cpu().numpy()))
+    rng = np.random.default_rng(99)
+    streams = [None, torch.cuda.Stream(), torch.cuda.Stream()]
+    pending = []
+    for it in range(60):
+        k = int(rng.integers(len(jobs)))
+        c, th, x, obs = jobs[k]
+        B = full[k][0].shape[0]
+        n_sel = int(rng.choice([1, 2, 5, B]))
+        sel = np.sort(rng.choice(B, n_sel, replace=False)).astype(np.int32)
+        params = None
+        if rng.random() < 0.25:
+            params = np.sort(rng.choice(c.n_theta, max(1, c.n_theta // 3), replace=False))
+        e, m = c.psr_full(th, x, sel=sel, obs_list=obs, n_marg_bits=1, stream=streams[int(rng.integers(3))], params=params)
+        pending.append((k, sel, params, e, m))
+        if len(pending) == 6 or it == 59:
+            torch.cuda.synchronize()
+            for k2, sel2, params2, e2, m2 in pending:
+                we, wm = full[k2][0][sel2], full[k2][1][sel2]
+                ge, gm = e2.cpu().numpy(), m2.cpu().numpy()
+                if params2 is None:
+                    assert np.array_equal(ge, we) and np.array_equal(gm, wm), f"sweep of circuit {k2}, samples {sel2}"
+                else:
+                    rows = np.concatenate([[0], 2 * params2 + 1, 2 * params2 + 2])
+                    assert np.array_equal(ge[:, rows], we[:, rows]) and np.array_equal(gm[:, rows], wm[:, rows]), \
+                        f"subset sweep of circuit {k2}, samples {sel2}"
+            pending = []
